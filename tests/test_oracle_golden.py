@@ -1,0 +1,137 @@
+"""Oracle vs the REFERENCE's own outputs (golden vectors from oracle/gen_golden.py).  CPU only.
+
+Pins every stage of the oracle to the reference: embedding/encodings (layers.npz, produced by calling the
+reference's maestro/layers functions directly), mask selection, full forward reconstructions, the four loss
+variants and gradients (c*.npz / ts_*.npz, produced by running the reference's MAE + SSLModule.compute_loss_rec).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import maestro_amd.conf as conf
+from oracle import layers as ol
+from oracle import mae as om
+from oracle.gen_golden import build_datasets, case_table, init_weights, make_batch
+
+CASES = case_table()
+COMMON = dict(interpolate="nearest", model="mae", num_levels=1, type_head="attentive", fac_abs_enc=1.0,
+              fac_date_enc=1.0)
+
+
+def _load(golden_dir, name):
+    return np.load(golden_dir / f"{name}.npz", allow_pickle=False)
+
+
+def build_case(name):
+    case = CASES[name]
+    ds = build_datasets(case, conf)
+    oracle = om.build_oracle(ds, conf.MaskConfig(), model_size=case["size"], fusion_mode=case["fusion"],
+                             inter_depth=case["inter_depth"], **COMMON, **case["model_kw"])
+    chk = init_weights(oracle, case["seed"])
+    return case, ds, oracle, chk
+
+
+def injected_rng(gold, oracle):
+    noise, struct = {}, {}
+    for key in gold.files:
+        if key.startswith("noise/"):
+            g = key.split("/", 1)[1]
+            noise[g] = torch.from_numpy(gold[key])
+            L = noise[g].shape[1]
+            bits = np.unpackbits(gold[f"struct/{g}"], axis=1)[:, :L].astype(bool)
+            struct[g] = torch.from_numpy(bits)[:, :, None]
+    return noise, struct
+
+
+def test_layer_vectors(golden_dir):
+    g = _load(golden_dir, "layers")
+    assert np.array_equal(ol.posemb_sincos_2d(12, 12, 40, 8).numpy(), g["posemb_12_12_40"])
+    tab = ol.posemb_sincos_2d(96, 96, 24, 8)
+    for grid in (3, 5, 15, 96):
+        np.testing.assert_allclose(ol.pool_pos_encoding(tab, grid).numpy(), g[f"pool_96_{grid}"], atol=1e-6)
+    dates, ref = torch.from_numpy(g["dates_in"]), torch.from_numpy(g["ref_date_in"])
+    np.testing.assert_array_equal(ol.encode_dates(dates, ref, 16, 8, 1.0, 2, 1).numpy(), g["encode_dates_g2_lb1"])
+    np.testing.assert_array_equal(ol.encode_dates(dates, ref, 12, 8, 0.5, 1, 2).numpy(), g["encode_dates_g1_lb2"])
+    pat, pix = ol.Patchify([[0, 1], [2]], 16, 4), ol.Pixelify(16, [[0, 1], [2]], 4)
+    for module, key in ((pat, "patchify_params"), (pix, "pixelify_params")):
+        flat, off = torch.from_numpy(g[key]), 0
+        with torch.no_grad():
+            for p in module.parameters():
+                p.copy_(flat[off:off + p.numel()].reshape(p.shape))
+                off += p.numel()
+    y = pat(torch.from_numpy(g["patchify_in"]))
+    np.testing.assert_allclose(y.detach().numpy(), g["patchify_out"], atol=2e-6)
+    img, mimg = pix(torch.from_numpy(g["pixelify_in"]), torch.from_numpy(g["pixelify_mask_in"]))
+    np.testing.assert_allclose(img.detach().numpy(), g["pixelify_out"], atol=2e-6)
+    assert np.array_equal(mimg.numpy(), g["pixelify_mask_out"])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_loss_grads_match_reference(golden_dir, name):
+    gold = _load(golden_dir, name)
+    case, ds, oracle, chk = build_case(name)
+    assert abs(chk - float(gold["weights_checksum"])) < 1e-6 * chk, "seeded weights differ from golden run"
+    batch = make_batch(ds.dataset, case["B"], case["seed"])
+    noise, struct = injected_rng(gold, oracle)
+    tie_free = {k.split("/", 1)[1]: bool(gold[k]) for k in gold.files if k.startswith("tie_free/")}
+    assert all(tie_free.values()), "golden cases are chosen tie-free for mask selection"
+    multi_mod_groups = {g for g in noise if sum(1 for _, gg in ds.dataset.groups if gg == g) > 1
+                        and case["fusion"] == "group"}
+
+    def run(reference_tie_order):
+        oracle.reference_tie_order = reference_tie_order
+        b = {k: v.clone() for k, v in batch.items()}
+        return oracle(b, "pretrain", noise=noise, struct_masks=struct)
+
+    # 1) the build's semantics (stable order): masks exact everywhere; pixels exact where the reference's
+    #    result does not depend on its implementation-defined tie order (single-modality groups)
+    b, rec, msk, _ = run(False)
+    group_of = dict(ds.dataset.groups) if case["fusion"] == "group" else {m: m for m in ds.dataset.inputs}
+    for m in rec:
+        P = ds.dataset.inputs[m].patch_size.mae
+        tok = msk[m][:, :, 0, ::P, ::P].flatten(2).numpy()
+        L = tok.shape[2]
+        ref_tok = np.unpackbits(gold[f"mask_tok/{m}"], axis=2)[:, :, :L].astype(bool)
+        assert np.array_equal(tok, ref_tok), f"{m}: mask indices differ from reference"
+        if group_of[m] not in multi_mod_groups:
+            np.testing.assert_allclose(rec[m].detach().numpy(), gold[f"pixels_rec/{m}"], atol=5e-5)
+        if gold[f"target/{m}"].size:
+            np.testing.assert_allclose(b[m].numpy(), gold[f"target/{m}"], atol=1e-6)  # rescale_elev target
+
+    # 2) reference tie order reproduced -> everything matches (tie order is the sole divergence)
+    b, rec, msk, _ = run(bool(multi_mod_groups))
+    for m in rec:
+        np.testing.assert_allclose(rec[m].detach().numpy(), gold[f"pixels_rec/{m}"], atol=5e-5)
+    nb = om.norm_bands_of(ds.dataset)
+    for loss in ("l2_norm", "l1_norm", "l2", "l1"):
+        val = om.compute_loss_rec(b, rec, msk, oracle.out_grid_size, nb, loss)
+        assert abs(val.item() - float(gold[f"loss_{loss}"])) < 2e-6 * max(1.0, abs(val.item())), loss
+    oracle.zero_grad()
+    om.compute_loss_rec(b, rec, msk, oracle.out_grid_size, nb, "l2_norm").backward()
+    grads = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
+    checked = 0
+    for key in gold.files:
+        if key.startswith("gradnorm/"):
+            k = key.split("/", 1)[1]
+            ref = float(gold[key])
+            assert abs(grads[k].double().norm().item() - ref) <= 2e-4 * ref + 1e-9, k
+            checked += 1
+        elif key.startswith("grad/"):
+            k = key.split("/", 1)[1]
+            np.testing.assert_allclose(grads[k].numpy(), gold[key], rtol=2e-3, atol=1e-7)
+    assert checked > 20
+    oracle.reference_tie_order = False
+
+
+def test_banker_rounding_and_stable_ties():
+    # round() is banker's rounding; SURVEY Q5: ties resolve to ascending index
+    assert [om.OracleMAE.num_masked(0.75, L) for L in (6, 10, 18, 225)] == [4, 8, 14, 169]
+    case, ds, oracle, _ = build_case("c1_spot")
+    noise = torch.tensor([[0.5, 0.0, 0.0, 0.2] * 16])
+    struct = (noise == 0)[:, :, None]
+    masked, visible, mask_rec = oracle.mask_indices(noise, struct, "spot")
+    k = masked.shape[1]
+    zeros = torch.nonzero(noise[0] == 0).flatten()
+    assert torch.equal(masked[0, :], torch.sort(torch.cat([zeros, torch.nonzero(noise[0] == 0.2).flatten()[: k - len(zeros)]])).values)
+    assert mask_rec.sum() == k and torch.equal(torch.sort(torch.cat([masked, visible], 1)).values[0], torch.arange(64))
