@@ -1,0 +1,148 @@
+/* C ABI of libmaestro_hip.so -- the MI355X (gfx950) kernels of MAESTRO's MAE pretraining hot path.
+ *
+ * The reference (IGNF/MAESTRO) is pure Python with no FFI of its own; the boundary it would bind
+ * is therefore one entry point per fused stage of the per-step path.  Each declaration cites the reference
+ * lines whose ATen/einops op sequence it replaces (paths relative to the reference root).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the caller unless noted;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*), never synchronises, allocates nothing, keeps no
+ *     global mutable state, re-entrant across streams/threads; graph-capturable;
+ *   - returns 0 on success, <0 for a bad argument, >0 = hipError_t; mh_last_error() gives a thread-local message;
+ *   - bf16 = raw uint16 bits; "f32" = float; row-major with explicit leading dimensions (in elements).
+ */
+#ifndef MAESTRO_HIP_H
+#define MAESTRO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* mh_last_error(void);
+int mh_version(void);
+
+/* ---------------------------------------------------------------------------------------------- GEMM (MFMA)
+ * C[M,N] = op(A) * op(B) (+ epilogue), bf16 operands, fp32 accumulation on v_mfma_f32_16x16x32_bf16.
+ *   layout 0 "NT": A[M,K] (lda), B[N,K] (ldb)      -- forward of nn.Linear / 1x1 conv / patch-embed conv
+ *   layout 1 "NN": A[M,K] (lda), B[K,N] (ldb)      -- dgrad:  dX = dY * W
+ *   layout 2 "TN": A[K,M] (lda), B[K,N] (ldb)      -- wgrad:  dW = dY^T * X   (K = tokens)
+ * Replaces: vit_pytorch Attention.to_qkv / to_out / FeedForward Linear (call sites maestro/ssl/mae.py:135-174),
+ * enc_to_dec Linear (mae.py:145-154), Patchify conv (maestro/layers/embed.py:48-60), Pixelify 1x1 conv
+ * (embed.py:139-151) and their autograd transposes.
+ * flags: bit0 out_f32 (else bf16) | bit1 +bias[N] | bit2 GELU(erf) (aux_out, if given, receives the bf16
+ *        pre-activation) | bit3 += res[M,N] f32 (ldr) | bit4 *= gelu'(aux_in[M,N] bf16) | bit5 atomic accumulate
+ *        into C (f32 only; split-K is applied automatically for layout 2).
+ * Requirements: K % 8 == 0, lda/ldb % 8 == 0, N % 4 == 0, ldc % 4 == 0, 16-byte aligned bases. */
+#define MH_GEMM_OUT_F32 1
+#define MH_GEMM_BIAS 2
+#define MH_GEMM_GELU 4
+#define MH_GEMM_RESIDUAL 8
+#define MH_GEMM_DGELU 16
+#define MH_GEMM_ATOMIC 32
+int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                 int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
+                 int ldaux, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- LayerNorm
+ * y = (x - mean) * rstd * gamma + beta over the last dim; x f32 [rows, dim] (residual stream), y bf16 or f32.
+ * Saves mean/rstd (f32 [rows]) for the backward.  Replaces nn.LayerNorm inside vit_pytorch Attention.norm,
+ * FeedForward.net[0] and Transformer.norm (call sites mae.py:135-174).  dim % 4 == 0, dim <= 4096. */
+int mh_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_is_f32, float* mean,
+                     float* rstd, int rows, int dim, float eps, void* stream);
+/* dx[rows,dim] f32 = (dres ? dres : 0) + LN-backward(dy); dgamma/dbeta f32 [dim] are ATOMICALLY accumulated
+ * (caller zeroes them once per step).  dy is bf16 (dy_is_f32=0) or f32. */
+int mh_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* gamma, const float* mean,
+                     const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta, int rows,
+                     int dim, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- attention
+ * Fused softmax(Q K^T * scale) V, no mask, no dropout (vit_pytorch Attention.forward; call sites mae.py:135-174).
+ * qkv: bf16 [B, N, 3, H, D] (= to_qkv output, chunk(3) then 'b n (h d) -> b h n d'); out: bf16 [B, N, H*D];
+ * lse: f32 [B, H, N] (natural-log sum-exp of the scaled scores, saved for the backward).  D in {32, 64}. */
+int mh_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, void* stream);
+/* dqkv bf16 [B,N,3,H,D] from dout bf16 [B,N,H*D]; delta: f32 workspace [B,H,N]. */
+int mh_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                int B, int N, int H, int D, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- patch embed
+ * Patch extraction for one band-group of one modality (maestro/layers/embed.py:31-34,57-60 'b d c (h p1) (w p2)'
+ * + maestro/train/model.py:211-229): img f32 [B*D, Ctot, S, S], channels [c0, c0+C) ->
+ *   cols   bf16 [B*D*g*g, Kpad]  im2col rows in (c, p1, p2) order (= Conv2d weight flattening), zero padded;
+ *   target f32  [B*D*g*g, P*P*Ctot] columns (p1*P+p2)*Ctot + c  (only written when target != NULL, c0 == 0 pass
+ *          handles ALL channels): patch-group-wise normalised per `norm_bands` groups (unbiased variance,
+ *          eps 1e-6) when normalise != 0, else the raw pixels.
+ * rescale_elev (mim.py:433-436): channel 1.. = 30*(ch0 - ch) applied on the fly (Ctot == C required). */
+int mh_patchify(const float* img, void* cols, float* target, int BD, int Ctot, int c0, int C, int S, int P,
+                int Kpad, const int* norm_bands, int n_norm_groups, int normalise, int rescale_elev, void* stream);
+
+/* GroupNorm(1, E) over the whole (tokens x E) image per (b, d) (embed.py:55,59-61), two phases:
+ * partial sums -> stats f32 [BD, 2] (mean, rstd); then apply + per-channel affine + positional + date encodings
+ * (mim.py:232-252, utils.py:103-173) writing straight into the group sequence:
+ *   xg[b, tok_off + d*L + l, :] = (y - mean)*rstd*gamma + beta + pos[l, :] + date[b*D_dates + d % D_dates, :8 tail]
+ * y: f32 [BD*L, E] conv output (bias already added).  date: f32 [B*Dd, 8] (last 8 channels), may be NULL. */
+int mh_groupnorm_stats(const float* y, float* partial, float* stats, int BD, int L, int E, float eps, void* stream);
+int mh_embed_finish(const float* y, const float* stats, const float* gamma, const float* beta, const float* pos,
+                    const float* date, float* xg, int B, int D, int Dd, int L, int E, int tok_off, int Lgroup,
+                    void* stream);
+/* Backward of conv-output GroupNorm: dy f32 [BD*L, E] from dxg (same indexing as xg); also dgamma/dbeta (atomic).
+ * Output dyc is bf16 [BD*L, E] (operand of the patch-embed wgrad GEMM) and dbias via mh_colsum. */
+int mh_embed_finish_bwd(const float* dxg, const float* y, const float* stats, const float* gamma, void* dyc,
+                        float* dgamma, float* dbeta, float* partial, int B, int D, int L, int E, int tok_off,
+                        int Lgroup, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- masking
+ * Random-mask token selection with STABLE tie order (maestro/ssl/mae.py:236-259; ties documented in DESIGN.md):
+ * noise f32 [B, L] (already multiplied by 1 - struct), k masked per row.  Outputs: visible_idx int32 [B, L-k]
+ * ascending, masked_idx int32 [B, k] ascending, mask u8 [B, L] (1 = masked).  L <= 4096. */
+int mh_mask_select(const float* noise, int* visible_idx, int* masked_idx, uint8_t* mask, int B, int L, int k,
+                   void* stream);
+/* Row gather  dst[b, j, :] = src[b, idx[b, j], :]  (f32 rows of `dim`), dst may live inside a longer sequence:
+ * dst row stride = dst_L rows per sample starting at dst_off (joint-encoder concat, mim.py:408-423). */
+int mh_gather_rows(const float* src, const int* idx, float* dst, int B, int src_L, int n_idx, int dim, int dst_L,
+                   int dst_off, void* stream);
+/* Scatter-add transpose of mh_gather_rows into a ZEROED dsrc (each row written once -> plain stores). */
+int mh_scatter_rows(const float* ddst, const int* idx, float* dsrc, int B, int src_L, int n_idx, int dim,
+                    int dst_L, int dst_off, void* stream);
+/* Decoder input assembly (mae.py:266-287 + mim.py:254-274):
+ *   xdec[b, t, :] = (mask[b,t] ? mask_token[tok_mod[t]] : y[b, rank_of_visible(t), :]) + pos[t, :] + date8
+ * y: f32 [B, n_vis, Dd]; inv: int32 [B, L] position of token t in the visible list (or -1); mask_token f32
+ * [n_mod_slots, Dd] with tok_slot int32 [L]; pos f32 [L, Dd] (pooled table rows per group token);
+ * date f32 [B, L_dates, 8] indexed through date_row int32 [L]. */
+int mh_unmask_assemble(const float* y, const int* inv, const float* mask_token, const int* tok_slot, const float* pos,
+                       const float* date, const int* date_row, int n_date_rows, float* xdec, int B, int L, int n_vis,
+                       int Dd, void* stream);
+/* Backward: dy[b, j, :] (f32, visible rows) and dmask_token[slot, :] += sum over masked tokens (atomic). */
+int mh_unmask_assemble_bwd(const float* dxdec, const int* visible_idx, const uint8_t* mask, const int* tok_slot,
+                           float* dy, float* dmask_token, int B, int L, int n_vis, int Dd, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- loss
+ * Masked reconstruction loss at patch layout (maestro/train/model.py:195-247): rec f32 [T, PPC] (pixelify GEMM
+ * output), target f32 [T, PPC] (mh_patchify), mask u8 [T] per token.  l1 (p=1) or l2 (p=2).
+ * Accumulates sum(e) and the masked element count into acc[2] (double), writes drec = coef * d e/d rec for masked
+ * tokens (bf16 [T, PPC], zero elsewhere) where coef = *scale (device scalar = w_mod / (sum_w * n_masked_elems)). */
+int mh_masked_loss(const float* rec, const float* target, const uint8_t* mask, double* acc, const float* scale,
+                   void* drec, int T, int PPC, int p, void* stream);
+/* Count masked tokens per modality segment and emit per-modality gradient scales + finalise the scalar loss. */
+int mh_loss_scales(const uint8_t* mask_group, const int* seg_begin, const int* seg_end, const int* seg_ppc,
+                   const float* seg_weight, int n_seg, int B, int Lgroup, float* scales, void* stream);
+int mh_loss_finalize(const double* acc, const float* seg_weight, int n_seg, float* loss, void* stream);
+/* Patch layout [BD*g*g, P*P*C] -> image [BD, C, S, S] ('(p1 p2 c) h w -> c (h p1) (w p2)', embed.py:153-160). */
+int mh_depatchify(const float* patches, float* img, int BD, int C, int S, int P, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- misc
+ * column sums: out[n] (+)= sum_m x[m, n]  (bias gradients); x bf16 or f32; atomically accumulated. */
+int mh_colsum(const void* x, int x_is_f32, float* out, int M, int N, int ld, void* stream);
+/* f32 -> bf16 cast of a flat buffer (weight shadow copies). */
+int mh_cast_bf16(const float* src, void* dst, long n, void* stream);
+/* Conv2d weight [E, C, P, P] f32 -> bf16 [E, Kpad] (zero padded K). */
+int mh_pack_conv_weight(const float* w, void* dst, int E, int K, int Kpad, void* stream);
+/* Fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, maestro/train/model.py:135-140):
+ * decoupled weight decay, bias correction; also refreshes the bf16 shadow copy.  step >= 1. */
+int mh_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float b1, float b2,
+             float eps, float wd, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

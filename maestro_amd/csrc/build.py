@@ -1,0 +1,79 @@
+"""Build libmaestro_hip.so (gfx950) from the .hip sources in this directory with hipcc.
+
+In-tree build: the shared object lands in ``maestro_amd/lib/`` so it travels with the repo snapshot to the GPU box
+(it is git-ignored, not gpurun-ignored).  Objects are cached per source by content hash.
+"""
+
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent
+ROOT = CSRC.parent.parent
+LIB_DIR = CSRC.parent / "lib"
+LIB = LIB_DIR / "libmaestro_hip.so"
+OBJ_DIR = CSRC / "build"
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found; the MI355X kernels cannot be built")
+
+
+def _digest(src: Path) -> str:
+    h = hashlib.sha256()
+    for f in [src, CSRC / "common.hpp", ROOT / "include" / "maestro_hip.h"]:
+        h.update(f.read_bytes())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    hipcc = _hipcc()
+    OBJ_DIR.mkdir(exist_ok=True)
+    LIB_DIR.mkdir(exist_ok=True)
+    sources = sorted(CSRC.glob("*.hip"))
+    jobs, objs = [], []
+    for src in sources:
+        obj = OBJ_DIR / f"{src.stem}.{_digest(src)}.o"
+        objs.append(obj)
+        if force or not obj.exists():
+            for old in OBJ_DIR.glob(f"{src.stem}.*.o"):
+                old.unlink()
+            jobs.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+        return r.stderr
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as ex:
+            for warn in ex.map(compile_one, jobs):
+                if verbose and warn:
+                    print(warn, file=sys.stderr)
+    if jobs or not LIB.exists():
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

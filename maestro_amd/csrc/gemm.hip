@@ -1,0 +1,275 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogues (see include/maestro_hip.h: mh_gemm_bf16).
+//
+// Tile 128x128x64 per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 4x4 v_mfma_f32_16x16x32_bf16 tiles).
+// Operands are register-staged into a double-buffered, swizzled LDS image (one barrier per K step):
+//   * K-minor operand ([rows][k], k contiguous in memory): 128-B LDS rows, 16-B chunk index XOR (row & 7),
+//     fragments by ds_read_b128 (conflict-free: 16-lane groups hit 16 distinct 16-B slots).
+//   * K-major operand ([k][cols], cols contiguous: dgrad B = W, wgrad A = dY and B = X): 256-B LDS rows,
+//     32-B chunk index XOR f(k), fragments by ds_read_b64_tr_b16 (hardware transpose) -- no transposed copies
+//     of weights or activations are ever materialised in HBM.
+// The MFMA is issued with swapped operands (D' = B_tile * A_tile^T) so every lane owns 4 CONSECUTIVE output
+// columns of one row: bias/residual/aux are read and C is written with 8/16-byte vectors.
+// Split-K + fp32 atomics (LDS-transposed so each wave instruction adds 256 contiguous bytes) serve the wgrad.
+#include "common.hpp"
+#include "../../include/maestro_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile, 16 KiB
+
+struct GemmParams {
+    const bf16_t* A; const bf16_t* B; void* C;
+    const float* bias; const float* res; const bf16_t* aux_in; bf16_t* aux_out;
+    int M, N, K, lda, ldb, ldc, ldr, ldaux, flags;
+    int tiles_m, tiles_n, k_per_split;
+};
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+__device__ __forceinline__ int kmajor_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+// ---- global -> registers (4 x 16 B per thread per operand tile)
+template <bool KMAJOR>
+__device__ __forceinline__ void load_tile(const bf16_t* __restrict__ P, int ld, int row0, int nrows, int k0, int kend,
+                                          u32x4 (&v)[4]) {
+    const int t = threadIdx.x;
+    if constexpr (!KMAJOR) {  // memory: P[row * ld + k]
+        const int c = t & 7, r = t >> 3;
+        const int gk = k0 + c * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int grow = row0 + r + 32 * i;
+            u32x4 z = {0, 0, 0, 0};
+            if (grow < nrows && gk < kend) z = *reinterpret_cast<const u32x4*>(P + (size_t)grow * ld + gk);
+            v[i] = z;
+        }
+    } else {  // memory: P[k * ld + col]
+        const int c = t & 15, kk = t >> 4;
+        const int gcol = row0 + c * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gk = k0 + kk + 16 * i;
+            u32x4 z = {0, 0, 0, 0};
+            if (gk < kend && gcol < nrows) z = *reinterpret_cast<const u32x4*>(P + (size_t)gk * ld + gcol);
+            v[i] = z;
+        }
+    }
+}
+
+// ---- registers -> swizzled LDS tile
+template <bool KMAJOR>
+__device__ __forceinline__ void store_tile(unsigned char* tile, const u32x4 (&v)[4]) {
+    const int t = threadIdx.x;
+    if constexpr (!KMAJOR) {
+        const int c = t & 7, r = t >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r + 32 * i;
+            *reinterpret_cast<u32x4*>(tile + row * 128 + ((c ^ (row & 7)) << 4)) = v[i];
+        }
+    } else {
+        const int c = t & 15, kk = t >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = kk + 16 * i;
+            *reinterpret_cast<u32x4*>(tile + k * 256 + ((((c >> 1) ^ kmajor_f(k)) << 5) | ((c & 1) << 4))) = v[i];
+        }
+    }
+}
+
+// ---- LDS -> MFMA fragment: 8 bf16 along k for row/col (rc0 + lane&15), k = 32*s + 8*(lane>>4) + j
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 read_frag(const unsigned char* tile, int rc0, int s) {
+    const int l = threadIdx.x & 63;
+    if constexpr (!KMAJOR) {
+        const int row = rc0 + (l & 15), ch = 4 * s + (l >> 4);
+        return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((ch ^ (row & 7)) << 4));
+    } else {
+        const int g = l >> 4, qrow = (l & 15) >> 2, p = l & 3, q = rc0 >> 4;
+        const int k_lo = 32 * s + 8 * g + qrow, k_hi = k_lo + 4;
+        const lds_u8* base = (const lds_u8*)tile;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(base + k_lo * 256 + (((q ^ kmajor_f(k_lo)) << 5) + p * 8)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(base + k_hi * 256 + (((q ^ kmajor_f(k_hi)) << 5) + p * 8)));
+        s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, r);
+    }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // A0 A1 B0 B1
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = blockIdx.y * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+
+    f32x4 acc[4][4];  // [j (n tile)][i (m tile)]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[4], rb[4];
+    if (nk > 0) {
+        load_tile<A_KMAJOR>(p.A, p.lda, m0, p.M, kbeg, kend, ra);
+        load_tile<B_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg, kend, rb);
+        store_tile<A_KMAJOR>(smem, ra);
+        store_tile<B_KMAJOR>(smem + 2 * TILE_BYTES, rb);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const unsigned char* ta = smem + cur * TILE_BYTES;
+        const unsigned char* tb = smem + (2 + cur) * TILE_BYTES;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            load_tile<A_KMAJOR>(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, ra);
+            load_tile<B_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, rb);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KMAJOR>(ta, wm + 16 * i, s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR>(tb, wn + 16 * j, s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+        }
+        if (more) {
+            store_tile<A_KMAJOR>(smem + (cur ^ 1) * TILE_BYTES, ra);
+            store_tile<B_KMAJOR>(smem + (2 + (cur ^ 1)) * TILE_BYTES, rb);
+        }
+        __syncthreads();
+    }
+
+    const int g = l >> 4, lm = l & 15;
+    if (p.flags & MH_GEMM_ATOMIC) {
+        // Transpose each wave's 64x64 fp32 tile through LDS (operand buffers are free now; last loop barrier passed)
+        // so that one wave instruction adds one 256-B row segment.
+        // Per wave a 32x65 fp32 staging region (8.1 KiB), two passes of 32 rows.
+        float* st = reinterpret_cast<float*>(smem) + w * (32 * 65);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int i = 2 * half; i < 2 * half + 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[(16 * (i - 2 * half) + lm) * 65 + 16 * j + 4 * g + r] = acc[j][i][r];
+            const int n = n0 + wn + l;
+            if (n < p.N) {
+                for (int rr = 0; rr < 32; ++rr) {
+                    const int m = m0 + wm + 32 * half + rr;
+                    if (m < p.M) atomicAdd(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, st[rr * 65 + l]);
+                }
+            }
+        }
+        return;
+    }
+
+    const bool out_f32 = p.flags & MH_GEMM_OUT_F32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm + 16 * i + lm;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn + 16 * j + 4 * g;
+            if (n >= p.N) continue;
+            f32x4 v = acc[j][i];
+            if (p.flags & MH_GEMM_BIAS) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+                v += b;
+            }
+            if (p.flags & MH_GEMM_GELU) {
+                if (p.aux_out) {
+                    u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(p.aux_out + (size_t)m * p.ldaux + n) = pk;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (p.flags & MH_GEMM_DGELU) {
+                const u32x2 pk = *reinterpret_cast<const u32x2*>(p.aux_in + (size_t)m * p.ldaux + n);
+                v[0] *= gelu_erf_grad(__uint_as_float(pk[0] << 16));
+                v[1] *= gelu_erf_grad(__uint_as_float(pk[0] & 0xffff0000u));
+                v[2] *= gelu_erf_grad(__uint_as_float(pk[1] << 16));
+                v[3] *= gelu_erf_grad(__uint_as_float(pk[1] & 0xffff0000u));
+            }
+            if (p.flags & MH_GEMM_RESIDUAL) {
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n);
+                v += r4;
+            }
+            if (out_f32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
+            } else {
+                u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                            int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in,
+                            void* aux_out, int ldaux, void* stream) {
+    MH_CHECK_ARG(layout >= 0 && layout <= 2, "mh_gemm_bf16: layout %d", layout);
+    MH_CHECK_ARG(M > 0 && N > 0 && K > 0, "mh_gemm_bf16: empty problem %d %d %d", M, N, K);
+    MH_CHECK_ARG(A && B && C, "mh_gemm_bf16: null operand");
+    MH_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0, "mh_gemm_bf16: lda/ldb must be multiples of 8 (%d, %d)", lda, ldb);
+    MH_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0, "mh_gemm_bf16: N and ldc must be multiples of 4 (%d, %d)", N, ldc);
+    MH_CHECK_ARG(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 == 0, "mh_gemm_bf16: bases must be 16-B aligned");
+    if (layout == 2) {
+        MH_CHECK_ARG(M % 8 == 0 && N % 8 == 0, "mh_gemm_bf16: TN needs M, N multiples of 8 (%d, %d)", M, N);
+    } else {
+        MH_CHECK_ARG(K % 8 == 0, "mh_gemm_bf16: K must be a multiple of 8 (%d)", K);
+        if (layout == 1) MH_CHECK_ARG(N % 8 == 0, "mh_gemm_bf16: NN needs N multiple of 8 (%d)", N);
+    }
+    MH_CHECK_ARG(!(flags & MH_GEMM_BIAS) || bias, "mh_gemm_bf16: bias flag without pointer");
+    MH_CHECK_ARG(!(flags & MH_GEMM_RESIDUAL) || (res && ldr % 4 == 0), "mh_gemm_bf16: residual needs pointer, ldr%%4==0");
+    MH_CHECK_ARG(!(flags & MH_GEMM_DGELU) || (aux_in && ldaux % 4 == 0), "mh_gemm_bf16: dgelu needs aux_in");
+    MH_CHECK_ARG(!(flags & MH_GEMM_GELU) || !aux_out || ldaux % 4 == 0, "mh_gemm_bf16: ldaux %% 4");
+    MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || (flags & MH_GEMM_OUT_F32), "mh_gemm_bf16: atomic needs f32 output");
+    MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || !(flags & ~(MH_GEMM_ATOMIC | MH_GEMM_OUT_F32)),
+                 "mh_gemm_bf16: atomic accumulate excludes other epilogues");
+
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
+    p.bias = bias; p.res = res; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.flags = flags;
+    p.tiles_m = ceil_div(M, BM); p.tiles_n = ceil_div(N, BN);
+    int splits = 1;
+    if (flags & MH_GEMM_ATOMIC) {  // fill the 256 CUs (2 workgroups each) when the output has few tiles
+        const int tiles = p.tiles_m * p.tiles_n;
+        const int ksteps = ceil_div(K, BK);
+        splits = max(1, min(min(512 / max(tiles, 1), ksteps / 4), 32));
+    }
+    const int ksteps_per = ceil_div(ceil_div(K, BK), splits);
+    p.k_per_split = ksteps_per * BK;
+    splits = ceil_div(K, p.k_per_split);
+    dim3 grid(p.tiles_m * p.tiles_n, splits), block(NT);
+    hipStream_t s = (hipStream_t)stream;
+    switch (layout) {
+        case 0: hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, s, p); break;
+    }
+    MH_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,99 @@
+"""GPU parity of mh_gemm_bf16 (all three operand layouts + fused epilogues) through the C ABI."""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _operands(layout, M, N, K, dev, integer):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K + layout)
+    if integer:  # exactly representable -> the fp32-accumulated result must be bit exact
+        a = torch.randint(-3, 4, (M, K), generator=g).float()
+        b = torch.randint(-2, 3, (K, N), generator=g).float()
+        a += (torch.arange(M)[:, None] % 3 == 0).float()  # asymmetric
+    else:
+        a = torch.randn(M, K, generator=g)
+        b = torch.randn(K, N, generator=g) / K**0.5
+    a, b = a.to(dev).bfloat16(), b.to(dev).bfloat16()
+    want = a.float() @ b.float()
+    A = a.contiguous() if layout in (0, 1) else a.t().contiguous()       # [M,K] or [K,M]
+    B = b.t().contiguous() if layout == 0 else b.contiguous()            # [N,K] or [K,N]
+    return A, B, want
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 192), (200, 72, 104), (16, 8, 8), (1000, 136, 1000)])
+def test_gemm_exact_integers(layout, shape):
+    from maestro_amd import hip
+    dev = _dev()
+    M, N, K = shape
+    if layout == 2 and M % 8:
+        M = (M + 7) // 8 * 8
+    A, B, want = _operands(layout, M, N, K, dev, integer=True)
+    C = torch.full((M, N), float("nan"), device=dev)
+    hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], C, N, hip.OUT_F32)
+    torch.cuda.synchronize()
+    assert torch.equal(C, want), f"max diff {(C - want).abs().max().item()}"
+    Cb = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
+    hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], Cb, N, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(Cb, want.bfloat16())
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_split_k_atomic(layout):
+    from maestro_amd import hip
+    dev = _dev()
+    M, N, K = 264, 200, 5000  # K = "tokens": not a multiple of anything
+    if layout != 2:
+        K = 5000 // 8 * 8
+    A, B, want = _operands(layout, M, N, K, dev, integer=True)
+    C = torch.ones((M, N), device=dev)
+    hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], C, N, hip.OUT_F32 | hip.ATOMIC)
+    torch.cuda.synchronize()
+    assert torch.equal(C, want + 1.0)
+
+
+def test_gemm_epilogues():
+    from maestro_amd import hip
+    dev = _dev()
+    M, N, K = 300, 264, 320
+    A, B, want = _operands(0, M, N, K, dev, integer=False)
+    g = torch.Generator().manual_seed(1)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    pre = want + bias
+    # bias + GELU with saved pre-activation
+    C = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    aux = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    hip.gemm(0, M, N, K, A, K, B, K, C, N, hip.BIAS | hip.GELU, bias=bias, aux_out=aux, ldaux=N)
+    torch.cuda.synchronize()
+    assert (aux.float() - pre).abs().max() < 2e-2
+    assert (C.float() - torch.nn.functional.gelu(pre)).abs().max() < 2e-2
+    # bias + residual, fp32 out (out-of-place residual stream)
+    C = torch.empty((M, N), device=dev)
+    hip.gemm(0, M, N, K, A, K, B, K, C, N, hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=bias, res=res, ldr=N)
+    torch.cuda.synchronize()
+    assert (C - (pre + res)).abs().max() < 1e-4 * K**0.5
+    # dgelu: C = acc * gelu'(aux)
+    C = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    hip.gemm(0, M, N, K, A, K, B, K, C, N, hip.DGELU, aux_in=aux, ldaux=N)
+    torch.cuda.synchronize()
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert (C.float() - want * x.grad).abs().max() < 3e-2
+
+
+def test_gemm_bad_arguments_fail_loudly():
+    from maestro_amd import hip
+    dev = _dev()
+    A = torch.zeros(8, 12, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(hip.HipExtensionError):
+        hip.gemm(0, 8, 8, 12, A, 12, A, 12, torch.zeros(8, 8, device=dev), 8, hip.OUT_F32)  # K % 8
