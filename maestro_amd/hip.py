@@ -32,7 +32,6 @@ def lib() -> ctypes.CDLL:
                 "(or __graft_entry__.build()).  The MAE hot path has no fallback implementation.")
         _lib = ctypes.CDLL(str(_LIB_PATH))
         _lib.mh_last_error.restype = ctypes.c_char_p
-        _lib.mh_adamw.argtypes = None
     return _lib
 
 
