@@ -45,16 +45,20 @@ int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const 
                  int ldaux, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- LayerNorm
- * y = (x - mean) * rstd * gamma + beta over the last dim; x f32 [rows, dim] (residual stream), y bf16 or f32.
- * Saves mean/rstd (f32 [rows]) for the backward.  Replaces nn.LayerNorm inside vit_pytorch Attention.norm,
- * FeedForward.net[0] and Transformer.norm (call sites mae.py:135-174).  dim % 4 == 0, dim <= 4096. */
-int mh_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_is_f32, float* mean,
-                     float* rstd, int rows, int dim, float eps, void* stream);
-/* dx[rows,dim] f32 = (dres ? dres : 0) + LN-backward(dy); dgamma/dbeta f32 [dim] are ATOMICALLY accumulated
- * (caller zeroes them once per step).  dy is bf16 (dy_is_f32=0) or f32. */
-int mh_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* gamma, const float* mean,
-                     const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta, int rows,
-                     int dim, void* stream);
+ * y = (x - mean) * rstd * gamma + beta over the last dim; x f32 (residual stream), y bf16 (GEMM operand) or f32.
+ * Rows are addressed as row(b, j) = b * L + off + j (j < n) on both sides, so the split / concat of group sequences
+ * around the joint encoder (maestro/ssl/mim.py:408-423) and the per-modality ungroup (maestro/layers/utils.py:50-100)
+ * are addressing, not copies.  Saves mean/rstd (f32 [B*n]).  Replaces nn.LayerNorm inside vit_pytorch
+ * Attention.norm, FeedForward.net[0] and Transformer.norm (call sites maestro/ssl/mae.py:135-174).
+ * dim % 4 == 0, dim <= 2048. */
+int mh_layernorm_fwd(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y, int y_L,
+                     int y_off, int y_is_f32, float* mean, float* rstd, int B, int n, int dim, float eps, void* stream);
+/* dx (f32, x's row map) = (dres ? dres : 0) + LN-backward(dy); optional bf16 copy dx_bf16 (operand of the next
+ * dgrad/wgrad GEMM).  dgamma/dbeta f32 [dim] are ATOMICALLY accumulated (caller zeroes grads once per step); pass
+ * both NULL to skip.  dy is bf16 (dy_is_f32 = 0) or f32, addressed with its own row map. */
+int mh_layernorm_bwd(const void* dy, int dy_L, int dy_off, int dy_is_f32, const float* x, int x_L, int x_off,
+                     const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
+                     void* dx_bf16, float* dgamma, float* dbeta, int B, int n, int dim, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- attention
  * Fused softmax(Q K^T * scale) V, no mask, no dropout (vit_pytorch Attention.forward; call sites mae.py:135-174).
@@ -66,79 +70,79 @@ int mh_attn_bwd(const void* qkv, const void* out, const void* dout, const float*
                 int B, int N, int H, int D, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- patch embed
- * Patch extraction for one band-group of one modality (maestro/layers/embed.py:31-34,57-60 'b d c (h p1) (w p2)'
- * + maestro/train/model.py:211-229): img f32 [B*D, Ctot, S, S], channels [c0, c0+C) ->
- *   cols   bf16 [B*D*g*g, Kpad]  im2col rows in (c, p1, p2) order (= Conv2d weight flattening), zero padded;
- *   target f32  [B*D*g*g, P*P*Ctot] columns (p1*P+p2)*Ctot + c  (only written when target != NULL, c0 == 0 pass
- *          handles ALL channels): patch-group-wise normalised per `norm_bands` groups (unbiased variance,
- *          eps 1e-6) when normalise != 0, else the raw pixels.
- * rescale_elev (mim.py:433-436): channel 1.. = 30*(ch0 - ch) applied on the fly (Ctot == C required). */
-int mh_patchify(const float* img, void* cols, float* target, int BD, int Ctot, int c0, int C, int S, int P,
-                int Kpad, const int* norm_bands, int n_norm_groups, int normalise, int rescale_elev, void* stream);
+ * Patch extraction of one modality (maestro/layers/embed.py:57-60 'b d c (h p1) (w p2)' + the loss target of
+ * maestro/train/model.py:211-229): img f32 [BD, Ctot, S, S] ->
+ *   cols   bf16 [BD*g*g, Kpad]  im2col rows in (c, p1, p2) order (= Conv2d weight flattening), zero padded;
+ *   target f32  [BD*g*g, P*P*Ctot] columns (p1*P+p2)*Ctot + c (optional): patch-group-wise normalised per
+ *          norm_bands group (device int array; unbiased variance, eps 1e-6) when normalise != 0, else raw pixels.
+ * rescale_elev (maestro/ssl/mim.py:433-436): channels >= 1 become 30*(ch0 - ch) on the fly. */
+int mh_patchify(const float* img, void* cols, float* target, int BD, int Ctot, int S, int P, int Kpad,
+                const int* norm_bands, int n_norm_groups, int normalise, int rescale_elev, void* stream);
 
-/* GroupNorm(1, E) over the whole (tokens x E) image per (b, d) (embed.py:55,59-61), two phases:
- * partial sums -> stats f32 [BD, 2] (mean, rstd); then apply + per-channel affine + positional + date encodings
- * (mim.py:232-252, utils.py:103-173) writing straight into the group sequence:
- *   xg[b, tok_off + d*L + l, :] = (y - mean)*rstd*gamma + beta + pos[l, :] + date[b*D_dates + d % D_dates, :8 tail]
- * y: f32 [BD*L, E] conv output (bias already added).  date: f32 [B*Dd, 8] (last 8 channels), may be NULL. */
+/* GroupNorm(1, E) over the whole (tokens x E) image per (b, d) (embed.py:55,59-61): chunked partial sums ->
+ * stats f32 [BD, 2] = (mean, rstd).  partial: f32 workspace of mh_groupnorm_partial_size() floats. */
 int mh_groupnorm_stats(const float* y, float* partial, float* stats, int BD, int L, int E, float eps, void* stream);
+int mh_groupnorm_partial_size(int BD, int L, int E);
+/* normalise + per-channel affine + positional + date encodings (mim.py:232-252, utils.py:103-173), written straight
+ * into the group sequence:  xg[b, tok_off + d*L + l, :] = (y - mean)*rstd*gamma + beta + pos[l, :] (+ date[b*D+d, :]
+ * on the last 8 channels).  y: f32 [B*D*L, E] conv output incl. bias; pos f32 [L, E]; date f32 [B*D, 8] or NULL. */
 int mh_embed_finish(const float* y, const float* stats, const float* gamma, const float* beta, const float* pos,
-                    const float* date, float* xg, int B, int D, int Dd, int L, int E, int tok_off, int Lgroup,
-                    void* stream);
-/* Backward of conv-output GroupNorm: dy f32 [BD*L, E] from dxg (same indexing as xg); also dgamma/dbeta (atomic).
- * Output dyc is bf16 [BD*L, E] (operand of the patch-embed wgrad GEMM) and dbias via mh_colsum. */
+                    const float* date, float* xg, int B, int D, int L, int E, int tok_off, int Lgroup, void* stream);
+/* Backward of the above w.r.t. the conv output: dyc bf16 [B*D*L, E] (A operand of the patch-embed wgrad GEMM);
+ * dgamma/dbeta atomically accumulated; sums: f32 workspace [B*D, 2]. */
 int mh_embed_finish_bwd(const float* dxg, const float* y, const float* stats, const float* gamma, void* dyc,
-                        float* dgamma, float* dbeta, float* partial, int B, int D, int L, int E, int tok_off,
-                        int Lgroup, void* stream);
-
-/* ---------------------------------------------------------------------------------------------- masking
- * Random-mask token selection with STABLE tie order (maestro/ssl/mae.py:236-259; ties documented in DESIGN.md):
- * noise f32 [B, L] (already multiplied by 1 - struct), k masked per row.  Outputs: visible_idx int32 [B, L-k]
- * ascending, masked_idx int32 [B, k] ascending, mask u8 [B, L] (1 = masked).  L <= 4096. */
-int mh_mask_select(const float* noise, int* visible_idx, int* masked_idx, uint8_t* mask, int B, int L, int k,
-                   void* stream);
-/* Row gather  dst[b, j, :] = src[b, idx[b, j], :]  (f32 rows of `dim`), dst may live inside a longer sequence:
- * dst row stride = dst_L rows per sample starting at dst_off (joint-encoder concat, mim.py:408-423). */
-int mh_gather_rows(const float* src, const int* idx, float* dst, int B, int src_L, int n_idx, int dim, int dst_L,
-                   int dst_off, void* stream);
-/* Scatter-add transpose of mh_gather_rows into a ZEROED dsrc (each row written once -> plain stores). */
-int mh_scatter_rows(const float* ddst, const int* idx, float* dsrc, int B, int src_L, int n_idx, int dim,
-                    int dst_L, int dst_off, void* stream);
-/* Decoder input assembly (mae.py:266-287 + mim.py:254-274):
- *   xdec[b, t, :] = (mask[b,t] ? mask_token[tok_mod[t]] : y[b, rank_of_visible(t), :]) + pos[t, :] + date8
- * y: f32 [B, n_vis, Dd]; inv: int32 [B, L] position of token t in the visible list (or -1); mask_token f32
- * [n_mod_slots, Dd] with tok_slot int32 [L]; pos f32 [L, Dd] (pooled table rows per group token);
- * date f32 [B, L_dates, 8] indexed through date_row int32 [L]. */
-int mh_unmask_assemble(const float* y, const int* inv, const float* mask_token, const int* tok_slot, const float* pos,
-                       const float* date, const int* date_row, int n_date_rows, float* xdec, int B, int L, int n_vis,
-                       int Dd, void* stream);
-/* Backward: dy[b, j, :] (f32, visible rows) and dmask_token[slot, :] += sum over masked tokens (atomic). */
-int mh_unmask_assemble_bwd(const float* dxdec, const int* visible_idx, const uint8_t* mask, const int* tok_slot,
-                           float* dy, float* dmask_token, int B, int L, int n_vis, int Dd, void* stream);
-
-/* ---------------------------------------------------------------------------------------------- loss
- * Masked reconstruction loss at patch layout (maestro/train/model.py:195-247): rec f32 [T, PPC] (pixelify GEMM
- * output), target f32 [T, PPC] (mh_patchify), mask u8 [T] per token.  l1 (p=1) or l2 (p=2).
- * Accumulates sum(e) and the masked element count into acc[2] (double), writes drec = coef * d e/d rec for masked
- * tokens (bf16 [T, PPC], zero elsewhere) where coef = *scale (device scalar = w_mod / (sum_w * n_masked_elems)). */
-int mh_masked_loss(const float* rec, const float* target, const uint8_t* mask, double* acc, const float* scale,
-                   void* drec, int T, int PPC, int p, void* stream);
-/* Count masked tokens per modality segment and emit per-modality gradient scales + finalise the scalar loss. */
-int mh_loss_scales(const uint8_t* mask_group, const int* seg_begin, const int* seg_end, const int* seg_ppc,
-                   const float* seg_weight, int n_seg, int B, int Lgroup, float* scales, void* stream);
-int mh_loss_finalize(const double* acc, const float* seg_weight, int n_seg, float* loss, void* stream);
+                        float* dgamma, float* dbeta, float* sums, int B, int D, int L, int E, int tok_off, int Lgroup,
+                        void* stream);
 /* Patch layout [BD*g*g, P*P*C] -> image [BD, C, S, S] ('(p1 p2 c) h w -> c (h p1) (w p2)', embed.py:153-160). */
 int mh_depatchify(const float* patches, float* img, int BD, int C, int S, int P, void* stream);
 
+/* ---------------------------------------------------------------------------------------------- masking
+ * Random-mask token selection with STABLE tie order (maestro/ssl/mae.py:236-259; ties: DESIGN.md): noise f32 [B, L],
+ * struct_mask u8 [B, L] or NULL (noise *= 1 - struct), k masked per row.  Outputs: visible_idx int32 [B, L-k]
+ * ascending, masked_idx int32 [B, k] ascending, inv int32 [B, L] (position in the visible list or -1),
+ * mask u8 [B, L] (1 = masked).  L <= 8192. */
+int mh_mask_select(const float* noise, const uint8_t* struct_mask, int* visible_idx, int* masked_idx, int* inv,
+                   uint8_t* mask, int B, int L, int k, void* stream);
+/* Row gather  dst[b, dst_off + j, :] = src[b, idx[b, j], :]  (f32 rows of `dim`); dst rows live inside a sequence of
+ * dst_L rows per sample (x[batch, unmasked_indices], mae.py:261, fused with the joint-encoder concat). */
+int mh_gather_rows(const float* src, const int* idx, float* dst, int B, int src_L, int n_idx, int dim, int dst_L,
+                   int dst_off, void* stream);
+/* Transpose of mh_gather_rows into a ZEROED dsrc (indices unique per sample -> plain stores). */
+int mh_scatter_rows(const float* ddst, const int* idx, float* dsrc, int B, int src_L, int n_idx, int dim, int dst_L,
+                    int dst_off, void* stream);
+/* Decoder input assembly (mae.py:266-287 + mim.py:254-274):
+ *   xdec[b,t,:] = (inv[b,t] < 0 ? mask_token[tok_slot[t]] : y[b, inv[b,t], :]) + pos[t,:] + date[b, date_row[t], :8 tail]
+ * y f32 [B, n_vis, Dd]; mask_token f32 [slots, Dd]; pos f32 [L, Dd]; date f32 [B, n_date_rows, 8] or NULL. */
+int mh_unmask_assemble(const float* y, const int* inv, const float* mask_token, const int* tok_slot, const float* pos,
+                       const float* date, const int* date_row, int n_date_rows, float* xdec, int B, int L, int n_vis,
+                       int Dd, void* stream);
+/* dmask_token[slot, :] += sum of dxdec rows of masked tokens t in [t_lo, t_hi) whose tok_slot == slot (atomic). */
+int mh_unmask_token_grad(const float* dxdec, const uint8_t* mask, const int* tok_slot, float* dmask_token, int B, int L,
+                         int Dd, int slot, int t_lo, int t_hi, void* stream);
+/* out[0] = number of masked tokens of all samples in group positions [t_lo, t_hi) (one modality). */
+int mh_count_masked(const uint8_t* mask, int B, int L, int t_lo, int t_hi, int* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- loss
+ * Masked reconstruction loss at patch layout (maestro/train/model.py:195-247) for one modality: rec f32 [B*Lm, PPC]
+ * (pixelify GEMM output), target f32 [B*Lm, PPC] (mh_patchify), mask_group u8 [B, Lgroup] (token (b,t) of the modality
+ * sits at tok_off + t).  p = 1 (l1*) or 2 (l2*).  With coef = weight / (n_masked[0] * PPC):
+ *   acc[0] += coef * sum(e over masked elements)   (weight = w_mod / sum_w  ->  acc accumulates the final loss)
+ *   drec (bf16 [B*Lm, PPC], optional) = coef * d e / d rec on masked tokens, 0 elsewhere. */
+int mh_masked_loss(const float* rec, const float* target, const uint8_t* mask_group, const int* n_masked, float weight,
+                   float* acc, void* drec, int B, int Lm, int Lgroup, int tok_off, int PPC, int p, void* stream);
+
 /* ---------------------------------------------------------------------------------------------- misc
- * column sums: out[n] (+)= sum_m x[m, n]  (bias gradients); x bf16 or f32; atomically accumulated. */
+ * column sums: out[n] += sum_m x[m, n]  (bias gradients); x bf16 or f32; atomically accumulated. */
 int mh_colsum(const void* x, int x_is_f32, float* out, int M, int N, int ld, void* stream);
 /* f32 -> bf16 cast of a flat buffer (weight shadow copies). */
 int mh_cast_bf16(const float* src, void* dst, long n, void* stream);
-/* Conv2d weight [E, C, P, P] f32 -> bf16 [E, Kpad] (zero padded K). */
-int mh_pack_conv_weight(const float* w, void* dst, int E, int K, int Kpad, void* stream);
-/* Fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, maestro/train/model.py:135-140):
- * decoupled weight decay, bias correction; also refreshes the bf16 shadow copy.  step >= 1. */
+/* f32 [E, K] -> bf16 [E, Kpad] (zero padded rows: patch-embed conv weight [E, C*P*P]) and the transpose for grads:
+ * dst f32 [E, K] += src f32 [E, Kpad][:, :K]. */
+int mh_pack_rows_bf16(const float* w, void* dst, int E, int K, int Kpad, void* stream);
+int mh_unpack_rows_add(const float* src, float* dst, int E, int K, int Kpad, void* stream);
+/* Fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, maestro/train/model.py:135-140): decoupled
+ * weight decay, bias correction, grads pre-multiplied by grad_scale; refreshes the bf16 shadow copy (optional).
+ * n % 4 == 0, step >= 1. */
 int mh_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float b1, float b2,
              float eps, float wd, int step, float grad_scale, void* stream);
 

@@ -1,0 +1,506 @@
+// Fused (flash-style) multi-head attention forward / backward for gfx950; head_dim D in {32, 64}, no mask, no dropout.
+// qkv bf16 [B, N, 3, H, D]; out / dout bf16 [B, N, H*D]; lse f32 [B, H, N]; arbitrary N (keys >= N masked to -inf).
+//
+// MFMA formulation (v_mfma_f32_16x16x32_bf16, D[row][col] = sum_k first[row][k] * second[k][col]):
+//   forward / dQ kernels keep the QUERY on the lane:   S^T[key][q] = K . Q^T,  O^T[d][q] = V^T . P^T
+//     -> softmax statistics (m, l), the rescale factor and delta/lse are per-lane scalars (no cross-lane traffic
+//        except one 2-step max exchange per KV tile), and the P^T accumulator IS the B operand of the next MFMA.
+//   dK/dV kernel keeps the KEY on the lane:             S[q][key] = Q . K^T,  dV^T[d][key] = dO^T . P,  dK^T = Q^T . dS
+// K/V (or Q/dO) tiles of 64 rows are staged in LDS twice when needed: a "row image" read by ds_read_b128 and a
+// "transpose image" read by ds_read_b64_tr_b16 (hardware transpose), both XOR-swizzled to be bank-conflict free.
+#include "common.hpp"
+#include "../../include/maestro_hip.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+template <int D> __device__ __forceinline__ int row_swz(int row) {
+    if constexpr (D == 64) return row & 7;
+    else return (0x78 >> (2 * ((row >> 2) & 3))) & 3;
+}
+template <int D> __device__ __forceinline__ int tr_swz(int row) {
+    if constexpr (D == 64) return (row >> 1) & 3;
+    else return (row >> 2) & 1;
+}
+
+// Stage a [64 rows][D] bf16 tile: global -> registers.  Row r of the tile is token (row0 + r); rows >= nrows give zeros.
+template <int D>
+__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ base, size_t row_stride, int row0, int nrows, u32x4 (&v)[2]) {
+    constexpr int CPR = D / 8;            // 16-B chunks per row
+    constexpr int RPI = 256 / CPR;        // rows per pass
+    const int t = threadIdx.x, c = t % CPR, r = t / CPR;
+#pragma unroll
+    for (int i = 0; i < 64 / RPI; ++i) {
+        const int row = r + RPI * i;
+        u32x4 z = {0, 0, 0, 0};
+        if (row0 + row < nrows) z = *reinterpret_cast<const u32x4*>(base + (size_t)(row0 + row) * row_stride + c * 8);
+        v[i] = z;
+    }
+}
+template <int D>
+__device__ __forceinline__ void tile_store_row(unsigned char* img, const u32x4 (&v)[2]) {
+    constexpr int CPR = D / 8, RPI = 256 / CPR;
+    const int t = threadIdx.x, c = t % CPR, r = t / CPR;
+#pragma unroll
+    for (int i = 0; i < 64 / RPI; ++i) {
+        const int row = r + RPI * i;
+        *reinterpret_cast<u32x4*>(img + row * (2 * D) + ((c ^ row_swz<D>(row)) << 4)) = v[i];
+    }
+}
+template <int D>
+__device__ __forceinline__ void tile_store_tr(unsigned char* img, const u32x4 (&v)[2]) {
+    constexpr int CPR = D / 8, RPI = 256 / CPR;
+    const int t = threadIdx.x, c = t % CPR, r = t / CPR;
+#pragma unroll
+    for (int i = 0; i < 64 / RPI; ++i) {
+        const int row = r + RPI * i;
+        *reinterpret_cast<u32x4*>(img + row * (2 * D) + ((((c >> 1) ^ tr_swz<D>(row)) << 5) | ((c & 1) << 4))) = v[i];
+    }
+}
+// first/second-operand fragment of rows (r0 + lane&15), k = d in [32*ks + 8*g, +8)
+template <int D>
+__device__ __forceinline__ bf16x8 frag_row(const unsigned char* img, int r0, int ks) {
+    const int l = threadIdx.x & 63, row = r0 + (l & 15), ch = 4 * ks + (l >> 4);
+    return *reinterpret_cast<const bf16x8*>(img + row * (2 * D) + ((ch ^ row_swz<D>(row)) << 4));
+}
+// transposed fragment: lane (col = 16*ct + lane&15, g): element j<4 -> row 32u + 4g + j ; j>=4 -> row 32u + 16 + 4g + (j-4)
+template <int D>
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* img, int ct, int u) {
+    const int l = threadIdx.x & 63, g = l >> 4, q = (l & 15) >> 2, p = l & 3;
+    const int r_lo = 32 * u + 4 * g + q, r_hi = r_lo + 16;
+    const lds_u8* b = (const lds_u8*)img;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(b + r_lo * (2 * D) + (((ct ^ tr_swz<D>(r_lo)) << 5) + p * 8)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(b + r_hi * (2 * D) + (((ct ^ tr_swz<D>(r_hi)) << 5) + p * 8)));
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+// load a B/A-operand fragment straight from global: row `tok` (or zeros), d in [32*ks + 8*g, +8)
+__device__ __forceinline__ bf16x8 frag_global(const bf16_t* __restrict__ base, size_t row_stride, int tok, int ntok, int ks) {
+    const int g = (threadIdx.x & 63) >> 4;
+    u32x4 z = {0, 0, 0, 0};
+    if (tok < ntok) z = *reinterpret_cast<const u32x4*>(base + (size_t)tok * row_stride + 32 * ks + 8 * g);
+    return __builtin_bit_cast(bf16x8, z);
+}
+// two accumulator tiles (rows 4g+r of tiles 2u, 2u+1) -> bf16x8 operand with the k-permutation of frag_tr
+__device__ __forceinline__ bf16x8 pack_acc(const f32x4& a, const f32x4& b) {
+    u32x4 r = {pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// =============================================================================================== forward
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                       float* __restrict__ lse, int N, int H, float scale) {
+    constexpr int KS = D / 32, DT = D / 16, TB = 64 * D * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TB];  // K row image | V transpose image
+    unsigned char* k_img = smem;
+    unsigned char* v_img = smem + TB;
+    const int b = blockIdx.z, h = blockIdx.y, q_blk = blockIdx.x * 128;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, lq = l & 15;
+    const size_t rs = (size_t)3 * H * D;                              // token stride in qkv
+    const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)h * D;       // q part
+    const bf16_t* kb = qb + (size_t)H * D;
+    const bf16_t* vb = qb + (size_t)2 * H * D;
+    const int q0 = q_blk + 32 * w;
+
+    bf16x8 qf[2][KS];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = frag_global(qb, rs, q0 + 16 * qt + lq, N, ks);
+
+    f32x4 o[2][DT];
+    float m[2], lsum[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        m[qt] = -INFINITY; lsum[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] = (f32x4){0, 0, 0, 0};
+    }
+    const float c = scale * LOG2E;
+    const int ntile = (N + 63) / 64;
+    u32x4 rk[2], rv[2];
+    tile_load<D>(kb, rs, 0, N, rk);
+    tile_load<D>(vb, rs, 0, N, rv);
+    for (int it = 0; it < ntile; ++it) {
+        const int kv0 = it * 64;
+        __syncthreads();  // previous tile fully consumed
+        tile_store_row<D>(k_img, rk);
+        tile_store_tr<D>(v_img, rv);
+        __syncthreads();
+        if (it + 1 < ntile) {
+            tile_load<D>(kb, rs, kv0 + 64, N, rk);
+            tile_load<D>(vb, rs, kv0 + 64, N, rv);
+        }
+        if (q0 >= N) continue;  // wave has no valid query: only helps staging
+        f32x4 s[2][4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const bf16x8 kf = frag_row<D>(k_img, 16 * kt, ks);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
+            }
+        const bool tail = kv0 + 64 > N;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = m[qt];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = s[qt][kt][r] * c;
+                    if (tail && kv0 + 16 * kt + 4 * g + r >= N) x = -INFINITY;
+                    s[qt][kt][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float alpha = exp2_fast(m[qt] - mx);  // first tile: exp2(-inf) = 0
+            m[qt] = mx;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp2_fast(s[qt][kt][r] - mx);
+                    s[qt][kt][r] = pv;
+                    ps += pv;
+                }
+            lsum[qt] = lsum[qt] * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+            pf[qt][0] = pack_acc(s[qt][0], s[qt][1]);
+            pf[qt][1] = pack_acc(s[qt][2], s[qt][3]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 vf = frag_tr<D>(v_img, dt, u);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][u], o[qt][dt], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + 16 * qt + lq;
+        float lt = lsum[qt];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        if (q >= N) continue;
+        const float inv = 1.f / lt;
+        bf16_t* orow = out + ((size_t)b * N + q) * H * D + (size_t)h * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const f32x4 v = o[qt][dt] * inv;
+            u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(orow + 16 * dt + 4 * g) = pk;
+        }
+        if (g == 0) lse[((size_t)b * H + h) * N + q] = (m[qt] + log2f(lt)) * 0.6931471805599453f;
+    }
+}
+
+// =============================================================================================== delta = rowsum(dO * O)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, int N, int H, int D, long total) {
+    // one thread group of D/8 lanes per (b, n, h) row
+    const int lanes = D / 8;
+    const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / lanes;
+    const int sub = threadIdx.x % lanes;
+    float s = 0.f;
+    if (gid < total) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(o + gid * D + sub * 8);
+        const u32x4 d = *reinterpret_cast<const u32x4*>(dout + gid * D + sub * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s += __uint_as_float(a[e] << 16) * __uint_as_float(d[e] << 16);
+            s += __uint_as_float(a[e] & 0xffff0000u) * __uint_as_float(d[e] & 0xffff0000u);
+        }
+    }
+    for (int off = lanes >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (gid < total && sub == 0) {
+        const long bn = gid / H; const int h = gid - bn * H; const long b = bn / N; const int n = bn - b * N;
+        delta[((size_t)b * H + h) * N + n] = s;
+    }
+}
+
+// =============================================================================================== dQ
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+    constexpr int KS = D / 32, DT = D / 16, TB = 64 * D * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * TB];  // K row | K transpose | V row
+    unsigned char* k_row = smem;
+    unsigned char* k_tr = smem + TB;
+    unsigned char* v_row = smem + 2 * TB;
+    const int b = blockIdx.z, h = blockIdx.y, q_blk = blockIdx.x * 128;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, lq = l & 15;
+    const size_t rs = (size_t)3 * H * D, os = (size_t)H * D;
+    const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)h * D;
+    const bf16_t* kb = qb + (size_t)H * D;
+    const bf16_t* vb = qb + (size_t)2 * H * D;
+    const bf16_t* dob = dout + (size_t)b * N * os + (size_t)h * D;
+    const int q0 = q_blk + 32 * w;
+
+    bf16x8 qf[2][KS], dof[2][KS];
+    float lse2[2], dlt[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + 16 * qt + lq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[qt][ks] = frag_global(qb, rs, q, N, ks);
+            dof[qt][ks] = frag_global(dob, os, q, N, ks);
+        }
+        lse2[qt] = q < N ? lse[((size_t)b * H + h) * N + q] * LOG2E : INFINITY;
+        dlt[qt] = q < N ? delta[((size_t)b * H + h) * N + q] : 0.f;
+    }
+    f32x4 dq[2][DT];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dq[qt][dt] = (f32x4){0, 0, 0, 0};
+    const float c = scale * LOG2E;
+    const int ntile = (N + 63) / 64;
+    u32x4 rk[2], rv[2];
+    tile_load<D>(kb, rs, 0, N, rk);
+    tile_load<D>(vb, rs, 0, N, rv);
+    for (int it = 0; it < ntile; ++it) {
+        const int kv0 = it * 64;
+        __syncthreads();
+        tile_store_row<D>(k_row, rk);
+        tile_store_tr<D>(k_tr, rk);
+        tile_store_row<D>(v_row, rv);
+        __syncthreads();
+        if (it + 1 < ntile) {
+            tile_load<D>(kb, rs, kv0 + 64, N, rk);
+            tile_load<D>(vb, rs, kv0 + 64, N, rv);
+        }
+        if (q0 >= N) continue;
+        f32x4 s[2][4], dp[2][4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) { s[qt][kt] = (f32x4){0, 0, 0, 0}; dp[qt][kt] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const bf16x8 kf = frag_row<D>(k_row, 16 * kt, ks);
+                const bf16x8 vf = frag_row<D>(v_row, 16 * kt, ks);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
+                    dp[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qt][ks], dp[qt][kt], 0, 0, 0);
+                }
+            }
+        const bool tail = kv0 + 64 > N;
+        bf16x8 dsf[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = exp2_fast(s[qt][kt][r] * c - lse2[qt]);
+                    if (tail && kv0 + 16 * kt + 4 * g + r >= N) pv = 0.f;
+                    s[qt][kt][r] = pv * (dp[qt][kt][r] - dlt[qt]) * scale;  // dS (w.r.t. raw q.k)
+                }
+            dsf[qt][0] = pack_acc(s[qt][0], s[qt][1]);
+            dsf[qt][1] = pack_acc(s[qt][2], s[qt][3]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 kt_f = frag_tr<D>(k_tr, dt, u);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) dq[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, dsf[qt][u], dq[qt][dt], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + 16 * qt + lq;
+        if (q >= N) continue;
+        bf16_t* drow = dqkv + ((size_t)b * N + q) * rs + (size_t)h * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const f32x4 v = dq[qt][dt];
+            u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(drow + 16 * dt + 4 * g) = pk;
+        }
+    }
+}
+
+// =============================================================================================== dK, dV
+// Workgroup = 128 keys (4 waves x 32 keys = 2 key tiles per wave); loops over 64-query tiles staged in LDS.
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+    constexpr int KS = D / 32, DT = D / 16, TB = 64 * D * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TB + 2 * 64 * 4];  // Q row | Q tr | dO row | dO tr | lse2 | delta
+    unsigned char* q_row = smem;
+    unsigned char* q_tr = smem + TB;
+    unsigned char* do_row = smem + 2 * TB;
+    unsigned char* do_tr = smem + 3 * TB;
+    float* s_lse = reinterpret_cast<float*>(smem + 4 * TB);
+    float* s_dlt = s_lse + 64;
+    const int b = blockIdx.z, h = blockIdx.y, k_blk = blockIdx.x * 128;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, lk = l & 15;
+    const size_t rs = (size_t)3 * H * D, os = (size_t)H * D;
+    const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)h * D;
+    const bf16_t* kb = qb + (size_t)H * D;
+    const bf16_t* vb = qb + (size_t)2 * H * D;
+    const bf16_t* dob = dout + (size_t)b * N * os + (size_t)h * D;
+    const int k0 = k_blk + 32 * w;
+
+    bf16x8 kf[2][KS], vf[2][KS];   // second operands: col = key
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[kt][ks] = frag_global(kb, rs, k0 + 16 * kt + lk, N, ks);
+            vf[kt][ks] = frag_global(vb, rs, k0 + 16 * kt + lk, N, ks);
+        }
+    f32x4 dk[2][DT], dv[2][DT];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { dk[kt][dt] = (f32x4){0, 0, 0, 0}; dv[kt][dt] = (f32x4){0, 0, 0, 0}; }
+    const float c = scale * LOG2E;
+    const int ntile = (N + 63) / 64;
+    u32x4 rq[2], rd[2];
+    tile_load<D>(qb, rs, 0, N, rq);
+    tile_load<D>(dob, os, 0, N, rd);
+    for (int it = 0; it < ntile; ++it) {
+        const int q0 = it * 64;
+        __syncthreads();
+        tile_store_row<D>(q_row, rq);
+        tile_store_tr<D>(q_tr, rq);
+        tile_store_row<D>(do_row, rd);
+        tile_store_tr<D>(do_tr, rd);
+        if (threadIdx.x < 64) {
+            const int q = q0 + threadIdx.x;
+            s_lse[threadIdx.x] = q < N ? lse[((size_t)b * H + h) * N + q] * LOG2E : INFINITY;
+            s_dlt[threadIdx.x] = q < N ? delta[((size_t)b * H + h) * N + q] : 0.f;
+        }
+        __syncthreads();
+        if (it + 1 < ntile) {
+            tile_load<D>(qb, rs, q0 + 64, N, rq);
+            tile_load<D>(dob, os, q0 + 64, N, rd);
+        }
+        if (k0 >= N) continue;
+        // S[q][key], dP[q][key]: rows = queries 16*qt + 4g + r, col = key
+        f32x4 s[4][2], dp[4][2];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) { s[qt][kt] = (f32x4){0, 0, 0, 0}; dp[qt][kt] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                const bf16x8 qfr = frag_row<D>(q_row, 16 * qt, ks);
+                const bf16x8 dfr = frag_row<D>(do_row, 16 * qt, ks);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kt][ks], s[qt][kt], 0, 0, 0);
+                    dp[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, vf[kt][ks], dp[qt][kt], 0, 0, 0);
+                }
+            }
+        bf16x8 pf[2][2], dsf[2][2];  // [kt][u]: k index = query permutation of frag_tr
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dlt + 16 * qt + 4 * g);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp2_fast(s[qt][kt][r] * c - l4[r]);  // query >= N: lse2 = +inf -> 0
+                    s[qt][kt][r] = pv;
+                    dp[qt][kt][r] = pv * (dp[qt][kt][r] - d4[r]) * scale;
+                }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                pf[kt][u] = pack_acc(s[2 * u][kt], s[2 * u + 1][kt]);
+                dsf[kt][u] = pack_acc(dp[2 * u][kt], dp[2 * u + 1][kt]);
+            }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 dot = frag_tr<D>(do_tr, dt, u);
+                const bf16x8 qt_f = frag_tr<D>(q_tr, dt, u);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    dv[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[kt][u], dv[kt][dt], 0, 0, 0);
+                    dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsf[kt][u], dk[kt][dt], 0, 0, 0);
+                }
+            }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = k0 + 16 * kt + lk;
+        if (key >= N) continue;
+        bf16_t* krow = dqkv + ((size_t)b * N + key) * rs + (size_t)H * D + (size_t)h * D;
+        bf16_t* vrow = krow + (size_t)H * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            u32x2 pk = {pack_bf2(dk[kt][dt][0], dk[kt][dt][1]), pack_bf2(dk[kt][dt][2], dk[kt][dt][3])};
+            u32x2 pv = {pack_bf2(dv[kt][dt][0], dv[kt][dt][1]), pack_bf2(dv[kt][dt][2], dv[kt][dt][3])};
+            *reinterpret_cast<u32x2*>(krow + 16 * dt + 4 * g) = pk;
+            *reinterpret_cast<u32x2*>(vrow + 16 * dt + 4 * g) = pv;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mh_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, void* stream) {
+    MH_CHECK_ARG(qkv && out && lse, "mh_attn_fwd: null pointer");
+    MH_CHECK_ARG(B > 0 && N > 0 && H > 0 && (D == 32 || D == 64), "mh_attn_fwd: unsupported shape B=%d N=%d H=%d D=%d", B, N, H, D);
+    MH_CHECK_ARG(H <= 65535 && B <= 65535, "mh_attn_fwd: grid limit");
+    dim3 grid(ceil_div(N, 128), H, B), block(256);
+    if (D == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
+    else hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                           int B, int N, int H, int D, float scale, void* stream) {
+    MH_CHECK_ARG(qkv && out && dout && lse && delta && dqkv, "mh_attn_bwd: null pointer");
+    MH_CHECK_ARG(B > 0 && N > 0 && H > 0 && (D == 32 || D == 64), "mh_attn_bwd: unsupported shape B=%d N=%d H=%d D=%d", B, N, H, D);
+    hipStream_t s = (hipStream_t)stream;
+    const long rows = (long)B * N * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div(rows * (D / 8), 256)), dim3(256), 0, s, (const bf16_t*)out,
+                       (const bf16_t*)dout, delta, N, H, D, rows);
+    dim3 grid(ceil_div(N, 128), H, B), block(256);
+    if (D == 64) {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+    }
+    MH_LAUNCH_CHECK();
+    return 0;
+}

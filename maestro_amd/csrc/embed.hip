@@ -1,0 +1,284 @@
+// Patch extraction, target normalisation, patch-embed GroupNorm (+ encodings) forward/backward.
+// See include/maestro_hip.h for the reference lines each entry point replaces.  All HBM-bound: coalesced row reads,
+// LDS transposes where the output order differs from the input order, wavefront reductions for statistics.
+#include "common.hpp"
+#include "../../include/maestro_hip.h"
+
+namespace {
+
+// Generic block reduction for blockDim.x in {64, 128, 256}.
+__device__ __forceinline__ float block_sum_any(float v, float* red) {
+    v = wave_sum(v);
+    const int nw = blockDim.x >> 6;
+    if (nw == 1) return v;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// One block per patch (token).  LDS holds the patch in TARGET order [(p1*P+p2)*Ctot + c].
+__global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ cols, float* __restrict__ target,
+                                int Ctot, int S, int P, int Kpad, const int* __restrict__ norm_bands, int n_groups,
+                                int normalise, int rescale_elev) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];  // P*P*Ctot floats + 8 reduction slots
+    const int g = S / P;
+    const int tok = blockIdx.x;  // (bd, ph, pw)
+    const int bd = tok / (g * g), pp = tok - bd * g * g, ph = pp / g, pw = pp - ph * g;
+    const int PP = P * P, K = Ctot * PP;
+    float* red = patch + K;
+    const float* base = img + ((size_t)bd * Ctot) * S * S + (size_t)(ph * P) * S + pw * P;
+    for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
+        float v = 0.f;
+        if (k < K) {
+            const int c = k / PP, r = k - c * PP, p1 = r / P, p2 = r - p1 * P;
+            v = base[(size_t)c * S * S + p1 * S + p2];
+            if (rescale_elev && c >= 1) v = 30.f * (base[p1 * S + p2] - v);
+            patch[r * Ctot + c] = v;
+        }
+        cols[(size_t)tok * Kpad + k] = f2bf(v);
+    }
+    if (!target) return;
+    __syncthreads();
+    float* out = target + (size_t)tok * K;
+    if (!normalise) {
+        for (int e = threadIdx.x; e < K; e += blockDim.x) out[e] = patch[e];
+        return;
+    }
+    // patch-group-wise statistics: unbiased variance, eps 1e-6 (reference model.py:226-229), two-pass
+    int c_lo = 0;
+    for (int gi = 0; gi < n_groups; ++gi) {
+        const int cg = norm_bands[gi], n = cg * PP;
+        float s = 0.f;
+        for (int e = threadIdx.x; e < n; e += blockDim.x) s += patch[(e / cg) * Ctot + c_lo + (e % cg)];
+        const float mu = block_sum_any(s, red) / n;
+        float q = 0.f;
+        for (int e = threadIdx.x; e < n; e += blockDim.x) {
+            const float d = patch[(e / cg) * Ctot + c_lo + (e % cg)] - mu;
+            q += d * d;
+        }
+        const float var = block_sum_any(q, red) / (n - 1);
+        const float inv = 1.f / sqrtf(var + 1.0e-6f);
+        for (int e = threadIdx.x; e < n; e += blockDim.x) {
+            const int idx = (e / cg) * Ctot + c_lo + (e % cg);
+            out[idx] = (patch[idx] - mu) * inv;
+        }
+        c_lo += cg;
+    }
+}
+
+// ---- GroupNorm(1, E) statistics over a whole (L x E) image: chunked partial sums, then a finalize.
+constexpr int GN_CHUNK = 8192;
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ y, float* __restrict__ partial,
+                                                         long per_image, int nchunk) {
+    __shared__ float red[8];
+    const int bd = blockIdx.y, ch = blockIdx.x;
+    const float* p = y + (size_t)bd * per_image;
+    const long lo = (long)ch * GN_CHUNK, hi = min(per_image, lo + GN_CHUNK);
+    float s = 0.f, q = 0.f;
+    for (long i = lo + threadIdx.x * 4; i < hi; i += 256 * 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+        q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    s = block_sum<4>(s, red);
+    q = block_sum<4>(q, red + 4);
+    if (threadIdx.x == 0) {
+        partial[((size_t)bd * nchunk + ch) * 2] = s;
+        partial[((size_t)bd * nchunk + ch) * 2 + 1] = q;
+    }
+}
+
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+                                                         long per_image, int nchunk, float eps) {
+    const int bd = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nchunk; i += 64) {
+        s += partial[((size_t)bd * nchunk + i) * 2];
+        q += partial[((size_t)bd * nchunk + i) * 2 + 1];
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (threadIdx.x == 0) {
+        const double mu = s / per_image;
+        const double var = fmax(q / per_image - mu * mu, 0.0);
+        stats[bd * 2] = (float)mu;
+        stats[bd * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// ---- normalise + affine + positional + date encodings, written into the group sequence. One wave per token.
+__global__ __launch_bounds__(256) void embed_finish_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ pos, const float* __restrict__ date,
+                                                           float* __restrict__ xg, int B, int D, int L, int E, int tok_off,
+                                                           int Lgroup) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * D * L) return;
+    const int bd = row / L, l = row - bd * L, b = bd / D, d = bd - b * D;
+    const float mu = stats[bd * 2], rs = stats[bd * 2 + 1];
+    const float* yr = y + (size_t)row * E;
+    float* o = xg + ((size_t)b * Lgroup + tok_off + d * L + l) * E;
+    const float* pr = pos + (size_t)l * E;
+    for (int c = lane * 4; c < E; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(yr + c);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+        const f32x4 ps = *reinterpret_cast<const f32x4*>(pr + c);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (v[e] - mu) * rs * g[e] + bt[e] + ps[e];
+        if (date && c >= E - 8) r += *reinterpret_cast<const f32x4*>(date + (size_t)bd * 8 + (c - (E - 8)));
+        *reinterpret_cast<f32x4*>(o + c) = r;
+    }
+}
+
+// ---- backward pass 1: per image S1 = sum(dz), S2 = sum(dz*z); dgamma/dbeta (atomic). ROWS tokens per wave.
+constexpr int EB_ROWS = 8;
+__global__ __launch_bounds__(256) void embed_bwd_stats_kernel(const float* __restrict__ dxg, const float* __restrict__ y,
+                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              float* __restrict__ sums, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int B, int D, int L, int E,
+                                                              int tok_off, int Lgroup) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][E]
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bd = blockIdx.y, b = bd / D, d = bd - b * D;
+    const float mu = stats[bd * 2], rs = stats[bd * 2 + 1];
+    float* rg = red + (size_t)w * 2 * E;
+    for (int c = lane; c < 2 * E; c += 64) rg[c] = 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    const int l0 = (blockIdx.x * 4 + w) * EB_ROWS;
+    for (int rr = 0; rr < EB_ROWS; ++rr) {
+        const int l = l0 + rr;
+        if (l >= L) break;
+        const float* yr = y + ((size_t)bd * L + l) * E;
+        const float* gr = dxg + ((size_t)b * Lgroup + tok_off + d * L + l) * E;
+        for (int c = lane * 4; c < E; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(yr + c);
+            const f32x4 dd = *reinterpret_cast<const f32x4*>(gr + c);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z = (v[e] - mu) * rs, dz = dd[e] * gm[e];
+                s1 += dz; s2 += dz * z;
+                rg[c + e] += dd[e] * z;       // lane-private columns: no race inside the wave
+                rg[E + c + e] += dd[e];
+            }
+        }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { atomicAdd(sums + bd * 2, s1); atomicAdd(sums + bd * 2 + 1, s2); }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * E; c += 256) {
+        const float t = red[c] + red[2 * E + c] + red[4 * E + c] + red[6 * E + c];
+        if (c < E) atomicAdd(dgamma + c, t); else atomicAdd(dbeta + (c - E), t);
+    }
+}
+
+// ---- backward pass 2: dy = rstd * (dz - S1/n - z*S2/n) as bf16 (A operand of the patch-embed wgrad GEMM)
+__global__ __launch_bounds__(256) void embed_bwd_apply_kernel(const float* __restrict__ dxg, const float* __restrict__ y,
+                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              const float* __restrict__ sums, bf16_t* __restrict__ dyc,
+                                                              int B, int D, int L, int E, int tok_off, int Lgroup) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * D * L) return;
+    const int bd = row / L, l = row - bd * L, b = bd / D, d = bd - b * D;
+    const float mu = stats[bd * 2], rs = stats[bd * 2 + 1];
+    const float n = (float)L * (float)E;
+    const float c1 = sums[bd * 2] / n, c2 = sums[bd * 2 + 1] / n;
+    const float* yr = y + (size_t)row * E;
+    const float* gr = dxg + ((size_t)b * Lgroup + tok_off + d * L + l) * E;
+    bf16_t* o = dyc + (size_t)row * E;
+    for (int c = lane * 4; c < E; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(yr + c);
+        const f32x4 dd = *reinterpret_cast<const f32x4*>(gr + c);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+        float r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float z = (v[e] - mu) * rs;
+            r[e] = rs * (dd[e] * gm[e] - c1 - z * c2);
+        }
+        u32x2 pk = {pack_bf2(r[0], r[1]), pack_bf2(r[2], r[3])};
+        *reinterpret_cast<u32x2*>(o + c) = pk;
+    }
+}
+
+// ---- patch layout -> image layout
+__global__ __launch_bounds__(256) void depatchify_kernel(const float* __restrict__ patches, float* __restrict__ img,
+                                                         int C, int S, int P, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // index into img [BD, C, S, S]
+    if (i >= total) return;
+    const int x = i % S; long r = i / S;
+    const int yy = r % S; r /= S;
+    const int c = r % C; const long bd = r / C;
+    const int g = S / P, ph = yy / P, p1 = yy - ph * P, pw = x / P, p2 = x - pw * P;
+    img[i] = patches[((bd * g + ph) * g + pw) * (long)(P * P * C) + (p1 * P + p2) * C + c];
+}
+
+}  // namespace
+
+extern "C" int mh_patchify(const float* img, void* cols, float* target, int BD, int Ctot, int S, int P, int Kpad,
+                           const int* norm_bands, int n_norm_groups, int normalise, int rescale_elev, void* stream) {
+    MH_CHECK_ARG(img && cols, "mh_patchify: null pointer");
+    MH_CHECK_ARG(S % P == 0 && Kpad >= Ctot * P * P && Kpad % 8 == 0, "mh_patchify: bad geometry S=%d P=%d Kpad=%d", S, P, Kpad);
+    MH_CHECK_ARG(!normalise || !target || (norm_bands && n_norm_groups > 0), "mh_patchify: norm_bands missing");
+    const int K = Ctot * P * P, g = S / P;
+    const int threads = K <= 128 ? 64 : 256;
+    const size_t lds = (size_t)(K + 8) * sizeof(float);
+    MH_CHECK_ARG(lds <= 64 * 1024, "mh_patchify: patch too large for LDS (%d floats)", K);
+    hipLaunchKernelGGL(patchify_kernel, dim3(BD * g * g), dim3(threads), lds, (hipStream_t)stream, img, (bf16_t*)cols,
+                       target, Ctot, S, P, Kpad, norm_bands, n_norm_groups, normalise, rescale_elev);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_groupnorm_stats(const float* y, float* partial, float* stats, int BD, int L, int E, float eps,
+                                  void* stream) {
+    MH_CHECK_ARG(y && partial && stats && E % 4 == 0, "mh_groupnorm_stats: bad arguments");
+    const long per_image = (long)L * E;
+    const int nchunk = ceil_div(per_image, GN_CHUNK);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, BD), dim3(256), 0, (hipStream_t)stream, y, partial, per_image, nchunk);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(BD), dim3(64), 0, (hipStream_t)stream, partial, stats, per_image, nchunk, eps);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_groupnorm_partial_size(int BD, int L, int E) { return BD * ceil_div((long)L * E, GN_CHUNK) * 2; }
+
+extern "C" int mh_embed_finish(const float* y, const float* stats, const float* gamma, const float* beta,
+                               const float* pos, const float* date, float* xg, int B, int D, int L, int E, int tok_off,
+                               int Lgroup, void* stream) {
+    MH_CHECK_ARG(y && stats && gamma && beta && pos && xg && E % 4 == 0 && E >= 8, "mh_embed_finish: bad arguments");
+    MH_CHECK_ARG(tok_off + D * L <= Lgroup, "mh_embed_finish: modality does not fit its group sequence");
+    hipLaunchKernelGGL(embed_finish_kernel, dim3(ceil_div((long)B * D * L, 4)), dim3(256), 0, (hipStream_t)stream, y, stats,
+                       gamma, beta, pos, date, xg, B, D, L, E, tok_off, Lgroup);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_embed_finish_bwd(const float* dxg, const float* y, const float* stats, const float* gamma, void* dyc,
+                                   float* dgamma, float* dbeta, float* sums, int B, int D, int L, int E, int tok_off,
+                                   int Lgroup, void* stream) {
+    MH_CHECK_ARG(dxg && y && stats && gamma && dyc && dgamma && dbeta && sums && E % 4 == 0, "mh_embed_finish_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)B * D * 2 * sizeof(float), s);
+    if (e != hipSuccess) return mh_fail((int)e, "mh_embed_finish_bwd: memset failed");
+    hipLaunchKernelGGL(embed_bwd_stats_kernel, dim3(ceil_div(L, 4 * EB_ROWS), B * D), dim3(256), (size_t)8 * E * sizeof(float), s,
+                       dxg, y, stats, gamma, sums, dgamma, dbeta, B, D, L, E, tok_off, Lgroup);
+    hipLaunchKernelGGL(embed_bwd_apply_kernel, dim3(ceil_div((long)B * D * L, 4)), dim3(256), 0, s, dxg, y, stats, gamma, sums,
+                       (bf16_t*)dyc, B, D, L, E, tok_off, Lgroup);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_depatchify(const float* patches, float* img, int BD, int C, int S, int P, void* stream) {
+    MH_CHECK_ARG(patches && img && S % P == 0, "mh_depatchify: bad arguments");
+    const long total = (long)BD * C * S * S;
+    hipLaunchKernelGGL(depatchify_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, patches, img, C, S, P, total);
+    MH_LAUNCH_CHECK();
+    return 0;
+}

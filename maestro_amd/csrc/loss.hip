@@ -1,0 +1,176 @@
+// Masked reconstruction loss at patch layout + its gradient, bias-gradient column sums, casts, fused AdamW.
+#include "common.hpp"
+#include "../../include/maestro_hip.h"
+
+namespace {
+
+// rec/target f32 [T, PPC] (token rows of ONE modality: T = B * Lm); mask_group u8 [B, Lgroup]; token (b, t) of the
+// modality sits at group position tok_off + t.  acc[0] += sum(e over masked), loss partial; drec (bf16) =
+// coef * de/drec for masked tokens, 0 elsewhere, with coef = weight / (n_masked_tokens * PPC).
+__global__ __launch_bounds__(256) void masked_loss_kernel(const float* __restrict__ rec, const float* __restrict__ target,
+                                                          const uint8_t* __restrict__ mask_group, const int* __restrict__ n_masked,
+                                                          float weight, float* __restrict__ acc, bf16_t* __restrict__ drec,
+                                                          int B, int Lm, int Lgroup, int tok_off, int PPC, int p) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;  // one block per token keeps it simple; PPC is 8 .. 2048
+    const int b = row / Lm, t = row - b * Lm;
+    const bool masked = mask_group[(size_t)b * Lgroup + tok_off + t] != 0;
+    const float coef = weight / ((float)(*n_masked) * (float)PPC);
+    const float* r = rec + (size_t)row * PPC;
+    const float* g = target + (size_t)row * PPC;
+    bf16_t* d = drec ? drec + (size_t)row * PPC : nullptr;
+    float s = 0.f;
+    for (int c = threadIdx.x * 4; c < PPC; c += 1024) {
+        float dd[4] = {0.f, 0.f, 0.f, 0.f};
+        if (masked) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(r + c);
+            const f32x4 tv = *reinterpret_cast<const f32x4*>(g + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float diff = rv[e] - tv[e];
+                if (p == 2) { s += diff * diff; dd[e] = 2.f * diff * coef; }
+                else { s += fabsf(diff); dd[e] = (diff > 0.f ? coef : (diff < 0.f ? -coef : 0.f)); }
+            }
+        }
+        if (d) {
+            u32x2 pk = {pack_bf2(dd[0], dd[1]), pack_bf2(dd[2], dd[3])};
+            *reinterpret_cast<u32x2*>(d + c) = pk;
+        }
+    }
+    if (!masked) return;  // block-uniform
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, s * coef);  // coef = weight / n_elems  ->  acc accumulates the weighted loss
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, int is_f32, float* __restrict__ out, int M,
+                                                     int N, int ld, int rows_per_block) {
+    __shared__ f32x4 red[4][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    f32x4 acc = {0, 0, 0, 0};
+    if (c < N) {
+        for (int r = r0 + w; r < r1; r += 4) {
+            if (is_f32) {
+                acc += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + (size_t)r * ld + c);
+            } else {
+                const u32x2 pk = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(x) + (size_t)r * ld + c);
+                acc += (f32x4){__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
+                               __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+            }
+        }
+    }
+    red[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && c < N) {
+        const f32x4 t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(out + c + e, t[e]);
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(dst + i) = pk;
+    } else {
+        for (long j = i; j < n; ++j) dst[j] = f2bf(src[j]);
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int E, int K, int Kpad) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)E * Kpad) return;
+    const int e = i / Kpad, k = i - (long)e * Kpad;
+    dst[i] = k < K ? f2bf(w[(size_t)e * K + k]) : (bf16_t)0;
+}
+
+__global__ __launch_bounds__(256) void unpack_rows_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int E, int K, int Kpad) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)E * K) return;
+    const int e = i / K, k = i - (long)e * K;
+    dst[i] += src[(size_t)e * Kpad + k];
+}
+
+// torch.optim.AdamW step (decoupled weight decay, bias correction), 4 elements per thread, grid-stride free.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i) * gscale;
+    f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
+    f32x4 mv = *reinterpret_cast<const f32x4*>(m + i);
+    f32x4 vv = *reinterpret_cast<const f32x4*>(v + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        pv[e] *= 1.f - lr * wd;
+        mv[e] = b1 * mv[e] + (1.f - b1) * gv[e];
+        vv[e] = b2 * vv[e] + (1.f - b2) * gv[e] * gv[e];
+        const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+        pv[e] -= (lr / bc1) * (mv[e] / denom);
+    }
+    *reinterpret_cast<f32x4*>(p + i) = pv;
+    *reinterpret_cast<f32x4*>(m + i) = mv;
+    *reinterpret_cast<f32x4*>(v + i) = vv;
+    if (pb) {
+        u32x2 pk = {pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3])};
+        *reinterpret_cast<u32x2*>(pb + i) = pk;
+    }
+}
+
+}  // namespace
+
+extern "C" int mh_masked_loss(const float* rec, const float* target, const uint8_t* mask_group, const int* n_masked,
+                              float weight, float* acc, void* drec, int B, int Lm, int Lgroup, int tok_off, int PPC, int p,
+                              void* stream) {
+    MH_CHECK_ARG(rec && target && mask_group && n_masked && acc, "mh_masked_loss: null pointer");
+    MH_CHECK_ARG((p == 1 || p == 2) && PPC % 4 == 0 && tok_off + Lm <= Lgroup, "mh_masked_loss: bad arguments");
+    hipLaunchKernelGGL(masked_loss_kernel, dim3(B * Lm), dim3(256), 0, (hipStream_t)stream, rec, target, mask_group, n_masked,
+                       weight, acc, (bf16_t*)drec, B, Lm, Lgroup, tok_off, PPC, p);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_colsum(const void* x, int x_is_f32, float* out, int M, int N, int ld, void* stream) {
+    MH_CHECK_ARG(x && out && N % 4 == 0 && ld % 4 == 0, "mh_colsum: bad arguments");
+    const int rows_per_block = 512;
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 256), ceil_div(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream, x,
+                       x_is_f32, out, M, N, ld, rows_per_block);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_cast_bf16(const float* src, void* dst, long n, void* stream) {
+    MH_CHECK_ARG(src && dst && n > 0, "mh_cast_bf16: bad arguments");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_pack_rows_bf16(const float* w, void* dst, int E, int K, int Kpad, void* stream) {
+    MH_CHECK_ARG(w && dst && Kpad >= K, "mh_pack_rows_bf16: bad arguments");
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div((long)E * Kpad, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, E, K, Kpad);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_unpack_rows_add(const float* src, float* dst, int E, int K, int Kpad, void* stream) {
+    MH_CHECK_ARG(src && dst && Kpad >= K, "mh_unpack_rows_add: bad arguments");
+    hipLaunchKernelGGL(unpack_rows_add_kernel, dim3(ceil_div((long)E * K, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, E, K, Kpad);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float b1, float b2,
+                        float eps, float wd, int step, float grad_scale, void* stream) {
+    MH_CHECK_ARG(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "mh_adamw: bad arguments (n %% 4 == 0, step >= 1)");
+    const float bc1 = 1.f - powf(b1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(b2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n, lr,
+                       b1, b2, eps, wd, bc1, bc2_sqrt, grad_scale);
+    MH_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,182 @@
+// Token masking: stable rank selection, visible-token gather / scatter, decoder-input assembly (+ backward).
+// Integer/index work is bit-exact by construction (counting rank = stable argsort).
+#include "common.hpp"
+#include "../../include/maestro_hip.h"
+
+namespace {
+
+// One block per sample.  rank_i = #{j : n_j < n_i} + #{j < i : n_j == n_i}  (stable ascending order);
+// masked <=> rank < k.  Positions inside the visible / masked lists are exclusive prefix counts (ascending index).
+__global__ __launch_bounds__(256) void mask_select_kernel(const float* __restrict__ noise, const uint8_t* __restrict__ smask,
+                                                          int* __restrict__ visible_idx, int* __restrict__ masked_idx,
+                                                          int* __restrict__ inv, uint8_t* __restrict__ mask, int L, int k) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // noise[L] then flags[L] (as int)
+    int* flag = reinterpret_cast<int*>(sm + L);
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < L; i += 256) {
+        float v = noise[(size_t)b * L + i];
+        if (smask && smask[(size_t)b * L + i]) v = 0.f;  // noise *= 1 - struct  (mae.py:240)
+        sm[i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += 256) {
+        const float v = sm[i];
+        int r = 0;
+        for (int j = 0; j < L; ++j) {
+            const float u = sm[j];
+            r += (u < v) || (u == v && j < i);
+        }
+        flag[i] = r < k;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += 256) {
+        int nm = 0;
+        for (int j = 0; j < i; ++j) nm += flag[j];
+        const int f = flag[i];
+        mask[(size_t)b * L + i] = (uint8_t)f;
+        if (f) {
+            masked_idx[(size_t)b * k + nm] = i;
+            inv[(size_t)b * L + i] = -1;
+        } else {
+            visible_idx[(size_t)b * (L - k) + (i - nm)] = i;
+            inv[(size_t)b * L + i] = i - nm;
+        }
+    }
+}
+
+// dst[b, dst_off + j, :] = src[b, idx[b, j], :]   (one wave per row)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                          float* __restrict__ dst, int B, int src_L, int n_idx, int dim,
+                                                          int dst_L, int dst_off) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * n_idx) return;
+    const int b = row / n_idx, j = row - b * n_idx;
+    const float* s = src + ((size_t)b * src_L + idx[row]) * dim;
+    float* d = dst + ((size_t)b * dst_L + dst_off + j) * dim;
+    for (int c = lane * 4; c < dim; c += 256) *reinterpret_cast<f32x4*>(d + c) = *reinterpret_cast<const f32x4*>(s + c);
+}
+
+// dsrc[b, idx[b, j], :] = ddst[b, dst_off + j, :]  (dsrc pre-zeroed; indices are unique per sample)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ ddst, const int* __restrict__ idx,
+                                                           float* __restrict__ dsrc, int B, int src_L, int n_idx, int dim,
+                                                           int dst_L, int dst_off) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * n_idx) return;
+    const int b = row / n_idx, j = row - b * n_idx;
+    float* s = dsrc + ((size_t)b * src_L + idx[row]) * dim;
+    const float* d = ddst + ((size_t)b * dst_L + dst_off + j) * dim;
+    for (int c = lane * 4; c < dim; c += 256) *reinterpret_cast<f32x4*>(s + c) = *reinterpret_cast<const f32x4*>(d + c);
+}
+
+// xdec[b,t,:] = (inv[b,t] < 0 ? mask_token[slot[t]] : y[b, inv[b,t], :]) + pos[t,:] + date8(b, date_row[t])
+__global__ __launch_bounds__(256) void unmask_kernel(const float* __restrict__ y, const int* __restrict__ inv,
+                                                     const float* __restrict__ mask_token, const int* __restrict__ tok_slot,
+                                                     const float* __restrict__ pos, const float* __restrict__ date,
+                                                     const int* __restrict__ date_row, int n_date_rows,
+                                                     float* __restrict__ xdec, int B, int L, int n_vis, int Dd) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * L) return;
+    const int b = row / L, t = row - b * L;
+    const int iv = inv[row];
+    const float* s = iv < 0 ? mask_token + (size_t)tok_slot[t] * Dd : y + ((size_t)b * n_vis + iv) * Dd;
+    const float* pr = pos + (size_t)t * Dd;
+    const float* dr = date ? date + ((size_t)b * n_date_rows + date_row[t]) * 8 : nullptr;
+    float* o = xdec + (size_t)row * Dd;
+    for (int c = lane * 4; c < Dd; c += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(s + c) + *reinterpret_cast<const f32x4*>(pr + c);
+        if (dr && c >= Dd - 8) v += *reinterpret_cast<const f32x4*>(dr + (c - (Dd - 8)));
+        *reinterpret_cast<f32x4*>(o + c) = v;
+    }
+}
+
+// dmask_token[slot] += sum over masked tokens; each block reduces a strip of token rows in registers first.
+constexpr int UM_ROWS = 16;
+__global__ __launch_bounds__(256) void unmask_bwd_token_kernel(const float* __restrict__ dxdec, const uint8_t* __restrict__ mask,
+                                                               const int* __restrict__ tok_slot, float* __restrict__ dmask_token,
+                                                               int B, int L, int Dd, int slot, int t_lo, int t_hi) {
+    // grid: (ceil(B*(t_hi-t_lo) / UM_ROWS)), 256 threads = Dd/4 <= 256 float4 columns ... Dd <= 1024
+    const int span = t_hi - t_lo;
+    const int r0 = blockIdx.x * UM_ROWS;
+    const int c = threadIdx.x * 4;
+    if (c >= Dd) return;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int rr = 0; rr < UM_ROWS; ++rr) {
+        const int r = r0 + rr;
+        if (r >= B * span) break;
+        const int b = r / span, t = t_lo + (r - b * span);
+        if (mask[(size_t)b * L + t] && tok_slot[t] == slot) acc += *reinterpret_cast<const f32x4*>(dxdec + ((size_t)b * L + t) * Dd + c);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (acc[e] != 0.f) atomicAdd(dmask_token + (size_t)slot * Dd + c + e, acc[e]);
+}
+
+__global__ __launch_bounds__(256) void count_masked_kernel(const uint8_t* __restrict__ mask, int B, int L, int t_lo, int t_hi,
+                                                           int* __restrict__ out) {
+    __shared__ float red[4];
+    const int span = t_hi - t_lo;
+    float c = 0.f;
+    for (int r = threadIdx.x; r < B * span; r += 256) {
+        const int b = r / span, t = t_lo + (r - b * span);
+        c += mask[(size_t)b * L + t] ? 1.f : 0.f;
+    }
+    c = block_sum<4>(c, red);
+    if (threadIdx.x == 0) *out = (int)(c + 0.5f);
+}
+
+}  // namespace
+
+extern "C" int mh_mask_select(const float* noise, const uint8_t* struct_mask, int* visible_idx, int* masked_idx, int* inv,
+                              uint8_t* mask, int B, int L, int k, void* stream) {
+    MH_CHECK_ARG(noise && visible_idx && masked_idx && inv && mask, "mh_mask_select: null pointer");
+    MH_CHECK_ARG(B > 0 && L > 0 && k >= 0 && k <= L && L <= 8192, "mh_mask_select: bad sizes B=%d L=%d k=%d", B, L, k);
+    hipLaunchKernelGGL(mask_select_kernel, dim3(B), dim3(256), (size_t)L * 8, (hipStream_t)stream, noise, struct_mask,
+                       visible_idx, masked_idx, inv, mask, L, k);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_gather_rows(const float* src, const int* idx, float* dst, int B, int src_L, int n_idx, int dim, int dst_L,
+                              int dst_off, void* stream) {
+    MH_CHECK_ARG(src && idx && dst && dim % 4 == 0 && dst_off + n_idx <= dst_L, "mh_gather_rows: bad arguments");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div((long)B * n_idx, 4)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, B,
+                       src_L, n_idx, dim, dst_L, dst_off);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_scatter_rows(const float* ddst, const int* idx, float* dsrc, int B, int src_L, int n_idx, int dim,
+                               int dst_L, int dst_off, void* stream) {
+    MH_CHECK_ARG(ddst && idx && dsrc && dim % 4 == 0 && dst_off + n_idx <= dst_L, "mh_scatter_rows: bad arguments");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(ceil_div((long)B * n_idx, 4)), dim3(256), 0, (hipStream_t)stream, ddst, idx, dsrc,
+                       B, src_L, n_idx, dim, dst_L, dst_off);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_unmask_assemble(const float* y, const int* inv, const float* mask_token, const int* tok_slot,
+                                  const float* pos, const float* date, const int* date_row, int n_date_rows, float* xdec,
+                                  int B, int L, int n_vis, int Dd, void* stream) {
+    MH_CHECK_ARG(y && inv && mask_token && tok_slot && pos && xdec && Dd % 4 == 0 && Dd >= 8, "mh_unmask_assemble: bad arguments");
+    MH_CHECK_ARG(!date || date_row, "mh_unmask_assemble: date without date_row");
+    hipLaunchKernelGGL(unmask_kernel, dim3(ceil_div((long)B * L, 4)), dim3(256), 0, (hipStream_t)stream, y, inv, mask_token,
+                       tok_slot, pos, date, date_row, n_date_rows, xdec, B, L, n_vis, Dd);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_unmask_token_grad(const float* dxdec, const uint8_t* mask, const int* tok_slot, float* dmask_token, int B,
+                                    int L, int Dd, int slot, int t_lo, int t_hi, void* stream) {
+    MH_CHECK_ARG(dxdec && mask && tok_slot && dmask_token && Dd % 4 == 0 && Dd <= 1024, "mh_unmask_token_grad: bad arguments");
+    MH_CHECK_ARG(0 <= t_lo && t_lo < t_hi && t_hi <= L, "mh_unmask_token_grad: bad token range");
+    hipLaunchKernelGGL(unmask_bwd_token_kernel, dim3(ceil_div((long)B * (t_hi - t_lo), UM_ROWS)), dim3(256), 0,
+                       (hipStream_t)stream, dxdec, mask, tok_slot, dmask_token, B, L, Dd, slot, t_lo, t_hi);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_count_masked(const uint8_t* mask, int B, int L, int t_lo, int t_hi, int* out, void* stream) {
+    MH_CHECK_ARG(mask && out && 0 <= t_lo && t_lo < t_hi && t_hi <= L, "mh_count_masked: bad arguments");
+    hipLaunchKernelGGL(count_masked_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mask, B, L, t_lo, t_hi, out);
+    MH_LAUNCH_CHECK();
+    return 0;
+}

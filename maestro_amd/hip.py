@@ -72,3 +72,98 @@ def call(name: str, *args) -> None:
         else:
             conv.append(a)
     _check(getattr(lib(), name)(*conv, stream()), name)
+
+
+# ------------------------------------------------------------------------------------------------ typed wrappers
+def layernorm_fwd(x, x_L, x_off, gamma, beta, y, y_L, y_off, mean, rstd, B, n, dim, eps=1e-5):
+    call("mh_layernorm_fwd", x, _I(x_L), _I(x_off), gamma, beta, y, _I(y_L), _I(y_off),
+         _I(1 if y.dtype == torch.float32 else 0), mean, rstd, _I(B), _I(n), _I(dim), _F(eps))
+
+
+def layernorm_bwd(dy, dy_L, dy_off, x, x_L, x_off, gamma, mean, rstd, dres, dx, dx_bf16, dgamma, dbeta, B, n, dim):
+    call("mh_layernorm_bwd", dy, _I(dy_L), _I(dy_off), _I(1 if dy.dtype == torch.float32 else 0), x, _I(x_L), _I(x_off),
+         gamma, mean, rstd, dres, dx, dx_bf16, dgamma, dbeta, _I(B), _I(n), _I(dim))
+
+
+def attn_fwd(qkv, out, lse, B, N, H, D, scale):
+    call("mh_attn_fwd", qkv, out, lse, _I(B), _I(N), _I(H), _I(D), _F(scale))
+
+
+def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):
+    call("mh_attn_bwd", qkv, out, dout, lse, delta, dqkv, _I(B), _I(N), _I(H), _I(D), _F(scale))
+
+
+def patchify(img, cols, target, BD, Ctot, S, P, Kpad, norm_bands, n_groups, normalise, rescale_elev):
+    call("mh_patchify", img, cols, target, _I(BD), _I(Ctot), _I(S), _I(P), _I(Kpad), norm_bands, _I(n_groups),
+         _I(int(normalise)), _I(int(rescale_elev)))
+
+
+def groupnorm_partial_size(BD, L, E) -> int:
+    return int(lib().mh_groupnorm_partial_size(_I(BD), _I(L), _I(E)))
+
+
+def groupnorm_stats(y, partial, stats, BD, L, E, eps=1e-5):
+    call("mh_groupnorm_stats", y, partial, stats, _I(BD), _I(L), _I(E), _F(eps))
+
+
+def embed_finish(y, stats, gamma, beta, pos, date, xg, B, D, L, E, tok_off, Lgroup):
+    call("mh_embed_finish", y, stats, gamma, beta, pos, date, xg, _I(B), _I(D), _I(L), _I(E), _I(tok_off), _I(Lgroup))
+
+
+def embed_finish_bwd(dxg, y, stats, gamma, dyc, dgamma, dbeta, sums, B, D, L, E, tok_off, Lgroup):
+    call("mh_embed_finish_bwd", dxg, y, stats, gamma, dyc, dgamma, dbeta, sums, _I(B), _I(D), _I(L), _I(E), _I(tok_off),
+         _I(Lgroup))
+
+
+def depatchify(patches, img, BD, C, S, P):
+    call("mh_depatchify", patches, img, _I(BD), _I(C), _I(S), _I(P))
+
+
+def mask_select(noise, struct_mask, visible_idx, masked_idx, inv, mask, B, L, k):
+    call("mh_mask_select", noise, struct_mask, visible_idx, masked_idx, inv, mask, _I(B), _I(L), _I(k))
+
+
+def gather_rows(src, idx, dst, B, src_L, n_idx, dim, dst_L, dst_off):
+    call("mh_gather_rows", src, idx, dst, _I(B), _I(src_L), _I(n_idx), _I(dim), _I(dst_L), _I(dst_off))
+
+
+def scatter_rows(ddst, idx, dsrc, B, src_L, n_idx, dim, dst_L, dst_off):
+    call("mh_scatter_rows", ddst, idx, dsrc, _I(B), _I(src_L), _I(n_idx), _I(dim), _I(dst_L), _I(dst_off))
+
+
+def unmask_assemble(y, inv, mask_token, tok_slot, pos, date, date_row, n_date_rows, xdec, B, L, n_vis, Dd):
+    call("mh_unmask_assemble", y, inv, mask_token, tok_slot, pos, date, date_row, _I(n_date_rows), xdec, _I(B), _I(L),
+         _I(n_vis), _I(Dd))
+
+
+def unmask_token_grad(dxdec, mask, tok_slot, dmask_token, B, L, Dd, slot, t_lo, t_hi):
+    call("mh_unmask_token_grad", dxdec, mask, tok_slot, dmask_token, _I(B), _I(L), _I(Dd), _I(slot), _I(t_lo), _I(t_hi))
+
+
+def count_masked(mask, B, L, t_lo, t_hi, out):
+    call("mh_count_masked", mask, _I(B), _I(L), _I(t_lo), _I(t_hi), out)
+
+
+def masked_loss(rec, target, mask_group, n_masked, weight, acc, drec, B, Lm, Lgroup, tok_off, PPC, p):
+    call("mh_masked_loss", rec, target, mask_group, n_masked, _F(weight), acc, drec, _I(B), _I(Lm), _I(Lgroup),
+         _I(tok_off), _I(PPC), _I(p))
+
+
+def colsum(x, out, M, N, ld):
+    call("mh_colsum", x, _I(1 if x.dtype == torch.float32 else 0), out, _I(M), _I(N), _I(ld))
+
+
+def cast_bf16(src, dst, n):
+    call("mh_cast_bf16", src, dst, _L(n))
+
+
+def pack_rows_bf16(w, dst, E, K, Kpad):
+    call("mh_pack_rows_bf16", w, dst, _I(E), _I(K), _I(Kpad))
+
+
+def unpack_rows_add(src, dst, E, K, Kpad):
+    call("mh_unpack_rows_add", src, dst, _I(E), _I(K), _I(Kpad))
+
+
+def adamw(p, g, m, v, p_bf16, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
+    call("mh_adamw", p, g, m, v, p_bf16, _L(n), _F(lr), _F(b1), _F(b2), _F(eps), _F(wd), _I(step), _F(grad_scale))

@@ -1,0 +1,312 @@
+"""GPU parity of the non-GEMM kernels (through the C ABI) against the oracle / fp32 references on the same inputs."""
+
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ----------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dim,B,n,xL,xoff,yL,yoff", [(768, 3, 50, 50, 0, 50, 0), (512, 2, 37, 64, 20, 40, 3),
+                                                      (192, 4, 16, 16, 0, 30, 14), (1024, 1, 9, 9, 0, 9, 0)])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_layernorm_fwd_bwd(dev, dim, B, n, xL, xoff, yL, yoff, out_f32):
+    from maestro_amd import hip
+    x = _rand(B, xL, dim, seed=1).to(dev) * 2 + 0.5
+    gamma, beta = (1 + 0.2 * _rand(dim, seed=2)).to(dev), (0.1 * _rand(dim, seed=3)).to(dev)
+    y = torch.full((B, yL, dim), 7.0, device=dev, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    mean, rstd = torch.empty(B * n, device=dev), torch.empty(B * n, device=dev)
+    hip.layernorm_fwd(x, xL, xoff, gamma, beta, y, yL, yoff, mean, rstd, B, n, dim)
+    xs = x[:, xoff:xoff + n].clone().requires_grad_(True)
+    g_ref, b_ref = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    want = F.layer_norm(xs, (dim,), g_ref, b_ref, 1e-5)
+    got = y[:, yoff:yoff + n].float()
+    assert (got - want).abs().max() < (1e-5 if out_f32 else 3e-2)
+    assert (y[:, :yoff].float() == 7).all() and (y[:, yoff + n:].float() == 7).all()
+    # backward
+    dy = _rand(B, yL, dim, seed=4).to(dev)
+    dy_in = dy if out_f32 else dy.bfloat16()
+    dres = _rand(B, xL, dim, seed=5).to(dev)
+    dx = torch.zeros(B, xL, dim, device=dev)
+    dxb = torch.zeros(B, xL, dim, device=dev, dtype=torch.bfloat16)
+    dg, db = torch.zeros(dim, device=dev), torch.zeros(dim, device=dev)
+    hip.layernorm_bwd(dy_in, yL, yoff, x, xL, xoff, gamma, mean, rstd, dres, dx, dxb, dg, db, B, n, dim)
+    want.backward(dy_in[:, yoff:yoff + n].float())
+    ref_dx = xs.grad + dres[:, xoff:xoff + n]
+    assert (dx[:, xoff:xoff + n] - ref_dx).abs().max() < 2e-4
+    assert (dxb[:, xoff:xoff + n].float() - ref_dx).abs().max() < 3e-2
+    assert (dg - g_ref.grad).abs().max() < 2e-3 and (db - b_ref.grad).abs().max() < 2e-3
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def _attn_ref(qkv, scale):
+    B, N, _, H, D = qkv.shape
+    q, k, v = (qkv[:, :, i].transpose(1, 2).float() for i in range(3))
+    s = torch.matmul(q, k.transpose(-1, -2)) * scale
+    o = torch.matmul(torch.softmax(s, -1), v)
+    return o.transpose(1, 2).reshape(B, N, H * D), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,N,H,D", [(2, 100, 3, 64), (1, 256, 2, 64), (2, 470, 1, 64), (2, 16, 3, 64),
+                                     (1, 1024, 2, 32), (3, 50, 4, 32), (2, 225, 2, 32), (1, 129, 1, 32)])
+def test_attention_fwd_bwd(dev, B, N, H, D):
+    from maestro_amd import hip
+    qkv = (_rand(B, N, 3, H, D, seed=N + D) * 1.5).to(dev).bfloat16()
+    scale = D**-0.5
+    out = torch.zeros(B, N, H * D, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, N, device=dev)
+    hip.attn_fwd(qkv, out, lse, B, N, H, D, scale)
+    ref = qkv.float().requires_grad_(True)
+    want, want_lse = _attn_ref(ref, scale)
+    assert (out.float() - want).abs().max() < 2e-2, (out.float() - want).abs().max().item()
+    assert (lse - want_lse).abs().max() < 2e-3
+    dout = _rand(B, N, H * D, seed=7).to(dev).bfloat16()
+    delta = torch.zeros(B, H, N, device=dev)
+    dqkv = torch.full((B, N, 3, H, D), float("nan"), device=dev, dtype=torch.bfloat16)
+    hip.attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale)
+    want.backward(dout.float())
+    err = (dqkv.float() - ref.grad).abs().max().item()
+    assert err < 3e-2 * max(1.0, ref.grad.abs().max().item()), err
+
+
+def test_attention_softmax_spike(dev):
+    """Forces a large running-max jump between KV tiles (online-softmax rescale branch)."""
+    from maestro_amd import hip
+    B, N, H, D = 1, 200, 1, 64
+    qkv = _rand(B, N, 3, H, D, seed=3).to(dev)
+    qkv[0, 5, 0] *= 6.0
+    qkv[0, 150, 1] = qkv[0, 5, 0] * 2.0  # key 150 (third tile) dominates query 5
+    qkv = qkv.bfloat16()
+    out = torch.zeros(B, N, H * D, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, N, device=dev)
+    hip.attn_fwd(qkv, out, lse, B, N, H, D, D**-0.5)
+    want, want_lse = _attn_ref(qkv.float(), D**-0.5)
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - want).abs().max() < 3e-2
+    assert ((lse - want_lse).abs() / want_lse.abs().clamp(min=1)).max() < 2e-3
+
+
+# ----------------------------------------------------------------------------------------------- patch embed
+@pytest.mark.parametrize("BD,C,S,P,norm_bands,elev", [(3, 4, 64, 16, (1, 3), False), (4, 10, 10, 2, (4, 4, 2), False),
+                                                       (2, 2, 64, 32, (2,), True), (2, 4, 100, 20, (1, 3), False),
+                                                       (5, 2, 6, 2, (1, 1), False), (2, 3, 64, 8, (3,), False)])
+@pytest.mark.parametrize("normalise", [True, False])
+def test_patchify(dev, BD, C, S, P, norm_bands, elev, normalise):
+    from maestro_amd import hip
+    from oracle import layers as ol
+    from oracle import mae as om
+    img = torch.rand(BD, C, S, S, generator=torch.Generator().manual_seed(S))
+    g = S // P
+    K = C * P * P
+    Kpad = (K + 31) // 32 * 32
+    cols = torch.full((BD * g * g, Kpad), 3.0, device=dev, dtype=torch.bfloat16)
+    target = torch.zeros(BD * g * g, K, device=dev)
+    nb = torch.tensor(norm_bands, dtype=torch.int32, device=dev)
+    hip.patchify(img.to(dev), cols, target, BD, C, S, P, Kpad, nb, len(norm_bands), normalise, elev)
+    ref_img = img.clone()
+    if elev:
+        ref_img[:, 1:] = 30 * (ref_img[:, :1] - ref_img[:, 1:])
+    want_cols = ol.im2col_patches(ref_img, P).reshape(-1, K)
+    assert torch.equal(cols[:, :K].cpu(), want_cols.bfloat16())
+    assert (cols[:, K:] == 0).all()
+    tgt = om.patch_view(ref_img[None], g)  # [1, BD, L, PP, C]
+    if normalise:
+        tgt = om.normalise_target(tgt, norm_bands)
+    assert (target.cpu() - tgt.reshape(-1, K)).abs().max() < 2e-4
+
+
+@pytest.mark.parametrize("B,D,L,E,tok_off,Lg", [(2, 1, 64, 192, 0, 64), (2, 3, 25, 768, 10, 100), (1, 4, 9, 1024, 36, 72)])
+def test_groupnorm_embed_finish_fwd_bwd(dev, B, D, L, E, tok_off, Lg):
+    from maestro_amd import hip
+    y = (_rand(B * D * L, E, seed=1) * 1.7 + 0.3).to(dev)
+    gamma, beta = (1 + 0.2 * _rand(E, seed=2)).to(dev), (0.1 * _rand(E, seed=3)).to(dev)
+    pos = _rand(L, E, seed=4).to(dev)
+    date = _rand(B * D, 8, seed=5).to(dev)
+    partial = torch.zeros(hip.groupnorm_partial_size(B * D, L, E), device=dev)
+    stats = torch.zeros(B * D, 2, device=dev)
+    hip.groupnorm_stats(y, partial, stats, B * D, L, E)
+    xg = torch.full((B, Lg, E), 5.0, device=dev)
+    hip.embed_finish(y, stats, gamma, beta, pos, date, xg, B, D, L, E, tok_off, Lg)
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    img = yr.reshape(B * D, L, E)
+    mu = img.mean(dim=(1, 2), keepdim=True)
+    var = ((img - mu) ** 2).mean(dim=(1, 2), keepdim=True)
+    z = (img - mu) / torch.sqrt(var + 1e-5) * gr + br
+    dpad = torch.cat([torch.zeros(B * D, E - 8, device=dev), date], dim=1)[:, None, :]
+    want = (z + pos[None] + dpad).reshape(B, D * L, E)
+    got = xg[:, tok_off:tok_off + D * L]
+    assert (got - want).abs().max() < 2e-4
+    assert (xg[:, :tok_off] == 5).all() and (xg[:, tok_off + D * L:] == 5).all()
+    # backward
+    dxg = torch.zeros(B, Lg, E, device=dev)
+    dxg[:, tok_off:tok_off + D * L] = _rand(B, D * L, E, seed=6).to(dev) * (torch.rand(B, D * L, 1, device=dev) < 0.3)
+    dyc = torch.zeros(B * D * L, E, device=dev, dtype=torch.bfloat16)
+    dg, db = torch.zeros(E, device=dev), torch.zeros(E, device=dev)
+    sums = torch.zeros(B * D, 2, device=dev)
+    hip.embed_finish_bwd(dxg, y, stats, gamma, dyc, dg, db, sums, B, D, L, E, tok_off, Lg)
+    want.backward(dxg[:, tok_off:tok_off + D * L])
+    scale = yr.grad.abs().max().item()
+    assert (dyc.float() - yr.grad).abs().max() < 2e-2 * scale
+    assert (dg - gr.grad).abs().max() < 1e-3 * max(1, gr.grad.abs().max().item())
+    assert (db - br.grad).abs().max() < 1e-3 * max(1, br.grad.abs().max().item())
+
+
+def test_depatchify(dev):
+    from maestro_amd import hip
+    from oracle import mae as om
+    BD, C, S, P = 3, 4, 32, 8
+    img = torch.rand(BD, C, S, S)
+    patches = om.patch_view(img[None], S // P).reshape(-1, P * P * C).to(dev)
+    out = torch.zeros(BD, C, S, S, device=dev)
+    hip.depatchify(patches, out, BD, C, S, P)
+    assert torch.equal(out.cpu(), img)
+
+
+# ----------------------------------------------------------------------------------------------- masking
+@pytest.mark.parametrize("B,L,k", [(4, 64, 48), (3, 1024, 768), (2, 225, 169), (5, 400, 300), (2, 72, 54)])
+def test_mask_select_matches_oracle(dev, B, L, k):
+    from maestro_amd import hip
+    g = torch.Generator().manual_seed(L)
+    noise = torch.rand(B, L, generator=g)
+    struct = torch.rand(B, L, generator=g) < 0.45
+    vis = torch.zeros(B, L - k, dtype=torch.int32, device=dev)
+    msk = torch.zeros(B, k, dtype=torch.int32, device=dev)
+    inv = torch.zeros(B, L, dtype=torch.int32, device=dev)
+    mask = torch.zeros(B, L, dtype=torch.uint8, device=dev)
+    hip.mask_select(noise.to(dev), struct.to(torch.uint8).to(dev), vis, msk, inv, mask, B, L, k)
+    nz = noise * (1 - struct.float())
+    order = torch.argsort(nz, dim=-1, stable=True)  # oracle semantics (oracle/mae.py mask_indices)
+    want_m = order[:, :k].sort(dim=1).values
+    want_v = order[:, k:].sort(dim=1).values
+    assert torch.equal(msk.cpu().long(), want_m) and torch.equal(vis.cpu().long(), want_v)
+    want_mask = torch.zeros(B, L, dtype=torch.bool).scatter_(1, want_m, True)
+    assert torch.equal(mask.cpu().bool(), want_mask)
+    pos = torch.full((B, L), -1, dtype=torch.long).scatter_(1, want_v, torch.arange(L - k).expand(B, -1))
+    assert torch.equal(inv.cpu().long(), pos)
+
+
+def test_gather_scatter_unmask(dev):
+    from maestro_amd import hip
+    B, L, n, dim, dst_L, off = 3, 40, 10, 64, 25, 7
+    src = _rand(B, L, dim, seed=1).to(dev)
+    idx = torch.stack([torch.randperm(L, generator=torch.Generator().manual_seed(b))[:n].sort().values for b in range(B)])
+    idx32 = idx.to(torch.int32).to(dev)
+    dst = torch.zeros(B, dst_L, dim, device=dev)
+    hip.gather_rows(src, idx32, dst, B, L, n, dim, dst_L, off)
+    want = src[torch.arange(B)[:, None], idx.to(dev)]
+    assert torch.equal(dst[:, off:off + n], want) and (dst[:, :off] == 0).all()
+    back = torch.zeros(B, L, dim, device=dev)
+    hip.scatter_rows(dst, idx32, back, B, L, n, dim, dst_L, off)
+    ref = torch.zeros(B, L, dim, device=dev)
+    ref[torch.arange(B)[:, None], idx.to(dev)] = want
+    assert torch.equal(back, ref)
+    # unmask assemble: two modality slots, date rows
+    Dd, n_vis = 32, n
+    y = _rand(B, n_vis, Dd, seed=2).to(dev)
+    inv = torch.full((B, L), -1, dtype=torch.int32)
+    for b in range(B):
+        inv[b, idx[b]] = torch.arange(n, dtype=torch.int32)
+    tok = _rand(2, Dd, seed=3).to(dev)
+    slot = (torch.arange(L) >= 24).to(torch.int32).to(dev)
+    pos = _rand(L, Dd, seed=4).to(dev)
+    date = _rand(B, 5, 8, seed=5).to(dev)
+    drow = (torch.arange(L) % 5).to(torch.int32).to(dev)
+    xdec = torch.zeros(B, L, Dd, device=dev)
+    hip.unmask_assemble(y, inv.to(dev), tok, slot, pos, date, drow, 5, xdec, B, L, n_vis, Dd)
+    ref = tok[slot.long()][None].repeat(B, 1, 1)
+    ref[torch.arange(B)[:, None], idx.to(dev)] = y
+    ref = ref + pos[None]
+    ref[:, :, Dd - 8:] += date[:, drow.long()]
+    assert (xdec - ref).abs().max() < 1e-6
+    mask = (inv < 0).to(torch.uint8).to(dev)
+    dtok = torch.zeros(2, Dd, device=dev)
+    dx = _rand(B, L, Dd, seed=6).to(dev)
+    hip.unmask_token_grad(dx, mask, slot, dtok, B, L, Dd, 0, 0, 24)
+    hip.unmask_token_grad(dx, mask, slot, dtok, B, L, Dd, 1, 24, L)
+    m = mask.bool()
+    want0 = (dx * (m & (slot == 0)[None])[:, :, None]).sum((0, 1))
+    want1 = (dx * (m & (slot == 1)[None])[:, :, None]).sum((0, 1))
+    assert (dtok[0] - want0).abs().max() < 1e-4 and (dtok[1] - want1).abs().max() < 1e-4
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    hip.count_masked(mask, B, L, 24, L, cnt)
+    assert cnt.item() == int(m[:, 24:].sum())
+
+
+# ----------------------------------------------------------------------------------------------- loss
+@pytest.mark.parametrize("p", [1, 2])
+@pytest.mark.parametrize("B,Lm,Lg,off,PPC", [(2, 16, 16, 0, 1024), (3, 36, 72, 36, 8), (2, 400, 400, 0, 40)])
+def test_masked_loss(dev, p, B, Lm, Lg, off, PPC):
+    from maestro_amd import hip
+    rec = _rand(B * Lm, PPC, seed=1).to(dev).requires_grad_(True)
+    target = _rand(B * Lm, PPC, seed=2).to(dev)
+    mask_group = (torch.rand(B, Lg, generator=torch.Generator().manual_seed(3)) < 0.7).to(torch.uint8).to(dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    hip.count_masked(mask_group, B, Lg, off, off + Lm, cnt)
+    acc = torch.zeros(1, device=dev)
+    drec = torch.full((B * Lm, PPC), 9.0, device=dev, dtype=torch.bfloat16)
+    weight = 0.37
+    hip.masked_loss(rec.detach(), target, mask_group, cnt, weight, acc, drec, B, Lm, Lg, off, PPC, p)
+    m = mask_group[:, off:off + Lm].reshape(-1).bool()
+    err = (target - rec).abs() if p == 1 else (target - rec) ** 2
+    want = weight * err[m].mean()
+    want.backward()
+    assert abs(acc.item() - want.item()) < 1e-5 * max(1, abs(want.item()))
+    scale = rec.grad.abs().max().item()
+    assert (drec.float() - rec.grad).abs().max() < 1e-2 * scale
+
+
+# ----------------------------------------------------------------------------------------------- misc
+def test_colsum_cast_pack_adamw(dev):
+    from maestro_amd import hip
+    M, N = 1000, 264
+    x = _rand(M, N, seed=1).to(dev)
+    out = torch.ones(N, device=dev)
+    hip.colsum(x, out, M, N, N)
+    assert (out - (1 + x.sum(0))).abs().max() < 1e-3
+    xb = x.bfloat16()
+    out.zero_()
+    hip.colsum(xb, out, M, N, N)
+    assert (out - xb.float().sum(0)).abs().max() < 1e-3
+    n = 4099
+    src = _rand(n, seed=2).to(dev)
+    dst = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+    hip.cast_bf16(src, dst, n)
+    assert torch.equal(dst, src.bfloat16())
+    E, K, Kpad = 10, 40, 64
+    w = _rand(E, K, seed=3).to(dev)
+    wp = torch.ones(E, Kpad, device=dev, dtype=torch.bfloat16)
+    hip.pack_rows_bf16(w, wp, E, K, Kpad)
+    assert torch.equal(wp[:, :K], w.bfloat16()) and (wp[:, K:] == 0).all()
+    acc = torch.ones(E, K, device=dev)
+    hip.unpack_rows_add(wp.float().contiguous(), acc, E, K, Kpad)
+    assert torch.equal(acc, 1 + w.bfloat16().float())
+    # AdamW vs torch.optim.AdamW over 3 steps
+    n = 4096
+    p0 = _rand(n, seed=4).to(dev)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([p_ref], lr=1e-2, betas=(0.9, 0.99), weight_decay=0.01)
+    p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pb = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+    for step in range(1, 4):
+        g = _rand(n, seed=10 + step).to(dev)
+        p_ref.grad = g.clone()
+        opt.step()
+        hip.adamw(p, g, m, v, pb, n, 1e-2, 0.9, 0.99, 1e-8, 0.01, step)
+    assert (p - p_ref.detach()).abs().max() < 1e-5
+    assert torch.equal(pb, p.bfloat16())
