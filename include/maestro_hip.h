@@ -85,14 +85,22 @@ int mh_groupnorm_stats(const float* y, float* partial, float* stats, int BD, int
 int mh_groupnorm_partial_size(int BD, int L, int E);
 /* normalise + per-channel affine + positional + date encodings (mim.py:232-252, utils.py:103-173), written straight
  * into the group sequence:  xg[b, tok_off + d*L + l, :] = (y - mean)*rstd*gamma + beta + pos[l, :] (+ date[b*D+d, :]
- * on the last 8 channels).  y: f32 [B*D*L, E] conv output incl. bias; pos f32 [L, E]; date f32 [B*D, 8] or NULL. */
+ * on the last 8 channels).  y: f32 [B*D*L, E] conv output incl. bias; pos f32 [L, E]; date f32 [B, date_rows, 8]
+ * (row date_off + d belongs to this modality's date d) or NULL. */
 int mh_embed_finish(const float* y, const float* stats, const float* gamma, const float* beta, const float* pos,
-                    const float* date, float* xg, int B, int D, int L, int E, int tok_off, int Lgroup, void* stream);
+                    const float* date, int date_rows, int date_off, float* xg, int B, int D, int L, int E, int tok_off,
+                    int Lgroup, void* stream);
 /* Backward of the above w.r.t. the conv output: dyc bf16 [B*D*L, E] (A operand of the patch-embed wgrad GEMM);
  * dgamma/dbeta atomically accumulated; sums: f32 workspace [B*D, 2]. */
 int mh_embed_finish_bwd(const float* dxg, const float* y, const float* stats, const float* gamma, void* dyc,
                         float* dgamma, float* dbeta, float* sums, int B, int D, int L, int E, int tok_off, int Lgroup,
                         void* stream);
+/* Date features (maestro/layers/utils.py:128-167): dates int16 [B, D, 3] (year, day-of-year, hour), ref_date int16
+ * [B, 1, 3] -> out f32 [B, rows, 8] rows [row_off, row_off + D): fac * [diff x4, sin/cos doy, sin/cos hour]. */
+int mh_date_features(const int16_t* dates, const int16_t* ref_date, float* out, int B, int D, int rows, int row_off,
+                     float fac, void* stream);
+/* Elevation rescale copy (maestro/ssl/mim.py:433-436): out[:, c>=1] = 30 * (img[:, 0] - img[:, c]); out != img. */
+int mh_rescale_elev(const float* img, float* out, int BD, int C, int S, void* stream);
 /* Patch layout [BD*g*g, P*P*C] -> image [BD, C, S, S] ('(p1 p2 c) h w -> c (h p1) (w p2)', embed.py:153-160). */
 int mh_depatchify(const float* patches, float* img, int BD, int C, int S, int P, void* stream);
 
@@ -116,7 +124,8 @@ int mh_scatter_rows(const float* ddst, const int* idx, float* dsrc, int B, int s
 int mh_unmask_assemble(const float* y, const int* inv, const float* mask_token, const int* tok_slot, const float* pos,
                        const float* date, const int* date_row, int n_date_rows, float* xdec, int B, int L, int n_vis,
                        int Dd, void* stream);
-/* dmask_token[slot, :] += sum of dxdec rows of masked tokens t in [t_lo, t_hi) whose tok_slot == slot (atomic). */
+/* dmask_token[:] (f32 [Dd], the gradient row of ONE mask token) += sum of dxdec rows of masked tokens t in
+ * [t_lo, t_hi) whose tok_slot == slot (atomic). */
 int mh_unmask_token_grad(const float* dxdec, const uint8_t* mask, const int* tok_slot, float* dmask_token, int B, int L,
                          int Dd, int slot, int t_lo, int t_hi, void* stream);
 /* out[0] = number of masked tokens of all samples in group positions [t_lo, t_hi) (one modality). */

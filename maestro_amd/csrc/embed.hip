@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ pos, const float* __restrict__ date,
                                                            float* __restrict__ xg, int B, int D, int L, int E, int tok_off,
-                                                           int Lgroup) {
+                                                           int Lgroup, int date_rows, int date_off) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= B * D * L) return;
     const int bd = row / L, l = row - bd * L, b = bd / D, d = bd - b * D;
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(const float* __restri
     const float* yr = y + (size_t)row * E;
     float* o = xg + ((size_t)b * Lgroup + tok_off + d * L + l) * E;
     const float* pr = pos + (size_t)l * E;
+    const float* dr = date ? date + ((size_t)b * date_rows + date_off + d) * 8 : nullptr;
     for (int c = lane * 4; c < E; c += 256) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(yr + c);
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(const float* __restri
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = (v[e] - mu) * rs * g[e] + bt[e] + ps[e];
-        if (date && c >= E - 8) r += *reinterpret_cast<const f32x4*>(date + (size_t)bd * 8 + (c - (E - 8)));
+        if (dr && c >= E - 8) r += *reinterpret_cast<const f32x4*>(dr + (c - (E - 8)));
         *reinterpret_cast<f32x4*>(o + c) = r;
     }
 }
@@ -219,7 +220,50 @@ __global__ __launch_bounds__(256) void depatchify_kernel(const float* __restrict
     img[i] = patches[((bd * g + ph) * g + pw) * (long)(P * P * C) + (p1 * P + p2) * C + c];
 }
 
+// ---- date features (maestro/layers/utils.py:128-167), same fp32 operation order as the reference:
+// out[b, row_off + d, :] = fac * [diff x4, sin(2pi doy/365.25), cos, sin(2pi hour/24), cos], diff = (year+doy')-(year_ref+doy_ref')
+__global__ __launch_bounds__(256) void date_features_kernel(const int16_t* __restrict__ dates, const int16_t* __restrict__ ref,
+                                                            float* __restrict__ out, int B, int D, int rows, int row_off, float fac) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, d = i - b * D;
+    const int16_t* dt = dates + (size_t)i * 3;
+    const float year = (float)dt[0], doy = (float)dt[1] / 365.25f, hour = (float)dt[2] / 24.0f;
+    const float year_ref = (float)ref[b * 3], doy_ref = (float)ref[b * 3 + 1] / 365.25f;
+    const float diff = (year + doy) - (year_ref + doy_ref);
+    const float a = 6.283185307179586f * doy, h = 6.283185307179586f * hour;
+    float* o = out + ((size_t)b * rows + row_off + d) * 8;
+    o[0] = o[1] = o[2] = o[3] = diff * fac;
+    o[4] = sinf(a) * fac; o[5] = cosf(a) * fac; o[6] = sinf(h) * fac; o[7] = cosf(h) * fac;
+}
+
+// ---- out = img with channels >= 1 replaced by 30 * (ch0 - ch)   (maestro/ssl/mim.py:433-436)
+__global__ __launch_bounds__(256) void rescale_elev_kernel(const float* __restrict__ img, float* __restrict__ out, int C, long plane, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long px = i % plane; const long r = i / plane; const int c = r % C; const long bd = r / C;
+    const float v = img[i];
+    out[i] = c == 0 ? v : 30.f * (img[(bd * C) * plane + px] - v);
+}
+
 }  // namespace
+
+extern "C" int mh_date_features(const int16_t* dates, const int16_t* ref_date, float* out, int B, int D, int rows, int row_off,
+                                float fac, void* stream) {
+    MH_CHECK_ARG(dates && ref_date && out && row_off + D <= rows, "mh_date_features: bad arguments");
+    hipLaunchKernelGGL(date_features_kernel, dim3(ceil_div(B * D, 256)), dim3(256), 0, (hipStream_t)stream, dates, ref_date, out, B, D,
+                       rows, row_off, fac);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_rescale_elev(const float* img, float* out, int BD, int C, int S, void* stream) {
+    MH_CHECK_ARG(img && out && img != out, "mh_rescale_elev: bad arguments (out of place only)");
+    const long plane = (long)S * S, total = (long)BD * C * plane;
+    hipLaunchKernelGGL(rescale_elev_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, img, out, C, plane, total);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int mh_patchify(const float* img, void* cols, float* target, int BD, int Ctot, int S, int P, int Kpad,
                            const int* norm_bands, int n_norm_groups, int normalise, int rescale_elev, void* stream) {
@@ -250,12 +294,12 @@ extern "C" int mh_groupnorm_stats(const float* y, float* partial, float* stats, 
 extern "C" int mh_groupnorm_partial_size(int BD, int L, int E) { return BD * ceil_div((long)L * E, GN_CHUNK) * 2; }
 
 extern "C" int mh_embed_finish(const float* y, const float* stats, const float* gamma, const float* beta,
-                               const float* pos, const float* date, float* xg, int B, int D, int L, int E, int tok_off,
-                               int Lgroup, void* stream) {
+                               const float* pos, const float* date, int date_rows, int date_off, float* xg, int B, int D,
+                               int L, int E, int tok_off, int Lgroup, void* stream) {
     MH_CHECK_ARG(y && stats && gamma && beta && pos && xg && E % 4 == 0 && E >= 8, "mh_embed_finish: bad arguments");
     MH_CHECK_ARG(tok_off + D * L <= Lgroup, "mh_embed_finish: modality does not fit its group sequence");
     hipLaunchKernelGGL(embed_finish_kernel, dim3(ceil_div((long)B * D * L, 4)), dim3(256), 0, (hipStream_t)stream, y, stats,
-                       gamma, beta, pos, date, xg, B, D, L, E, tok_off, Lgroup);
+                       gamma, beta, pos, date, xg, B, D, L, E, tok_off, Lgroup, date_rows, date_off);
     MH_LAUNCH_CHECK();
     return 0;
 }

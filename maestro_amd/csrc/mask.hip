@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void unmask_kernel(const float* __restrict__ y
     }
 }
 
-// dmask_token[slot] += sum over masked tokens; each block reduces a strip of token rows in registers first.
+// dmask_token[:] (ONE row = the gradient of modality `slot`'s mask token) += sum over its masked tokens; each block reduces a strip of token rows in registers first.
 constexpr int UM_ROWS = 16;
 __global__ __launch_bounds__(256) void unmask_bwd_token_kernel(const float* __restrict__ dxdec, const uint8_t* __restrict__ mask,
                                                                const int* __restrict__ tok_slot, float* __restrict__ dmask_token,
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void unmask_bwd_token_kernel(const float* __re
         if (mask[(size_t)b * L + t] && tok_slot[t] == slot) acc += *reinterpret_cast<const f32x4*>(dxdec + ((size_t)b * L + t) * Dd + c);
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) if (acc[e] != 0.f) atomicAdd(dmask_token + (size_t)slot * Dd + c + e, acc[e]);
+    for (int e = 0; e < 4; ++e) if (acc[e] != 0.f) atomicAdd(dmask_token + c + e, acc[e]);
 }
 
 __global__ __launch_bounds__(256) void count_masked_kernel(const uint8_t* __restrict__ mask, int B, int L, int t_lo, int t_hi,

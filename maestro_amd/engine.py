@@ -1,0 +1,479 @@
+"""Step engine of the MI355X MAE pretraining path: static buffers + a fixed sequence of HIP kernel launches.
+
+One engine = one (model, per-GPU batch size, loss) triple.  Everything the step touches is allocated once
+(activations for the backward, gradients, bf16 weight shadows), shapes never change between steps (the number of
+visible tokens per group is constant), so a step is a straight-line list of C-ABI calls on the current HIP stream
+-- capturable in a hipGraph.  PyTorch provides device memory and the stream only; every FLOP and byte of the hot path
+goes through libmaestro_hip.so (include/maestro_hip.h).  No CPU / PyTorch fallback exists.
+
+Pipeline (reference ``maestro/ssl/mim.py:473-505`` + ``maestro/train/model.py:195-247``):
+
+  patchify (+ normalised target)  ->  patch-embed GEMM  ->  GroupNorm + pos/date enc into the group sequence
+  ->  mask select (stable rank)  ->  gather visible rows  ->  per-group encoder  ->  final LN into the joint
+  sequence  ->  joint encoder  ->  final LN per group  ->  enc_to_dec GEMM  ->  unmask/assemble (+ dec encodings)
+  ->  decoder  ->  final LN per modality  ->  pixelify GEMM  ->  masked loss (+ d loss / d rec)
+  and the exact transpose of all of it for the backward, weight gradients accumulated into one flat fp32 buffer.
+"""
+
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from maestro_amd import hip
+from maestro_amd.layers.utils import draw_struct_masks
+
+F32, BF16, I32, U8 = torch.float32, torch.bfloat16, torch.int32, torch.uint8
+ALIGN = 64  # elements; keeps every parameter view 256-byte aligned
+
+
+# ======================================================================================= flat parameter storage
+class ParamStore:
+    """All trainable parameters as views of ONE flat fp32 buffer (+ flat grad, + flat bf16 shadow)."""
+
+    def __init__(self, ordered: list[tuple[str, nn.Parameter]], device) -> None:
+        self.names, self.offset, self.params = [], {}, []
+        off = 0
+        for name, p in ordered:
+            if id(p) in self.offset:  # shared parameter registered under two names
+                continue
+            self.names.append(name)
+            self.offset[id(p)] = off
+            self.params.append(p)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.flat = torch.zeros(off, dtype=F32, device=device)
+        self.grad = torch.zeros(off, dtype=F32, device=device)
+        self.half = torch.zeros(off, dtype=BF16, device=device)
+        for p in self.params:
+            o = self.offset[id(p)]
+            view = self.flat[o: o + p.numel()].view(p.shape)
+            view.copy_(p.data.to(device))
+            p.data = view
+            p.grad = self.grad[o: o + p.numel()].view(p.shape)
+        self._version = None
+
+    def g(self, p) -> torch.Tensor:
+        o = self.offset[id(p)]
+        return self.grad[o: o + p.numel()].view(p.shape)
+
+    def h(self, p) -> torch.Tensor:
+        o = self.offset[id(p)]
+        return self.half[o: o + p.numel()].view(p.shape)
+
+    def span(self, params) -> tuple[int, int]:
+        offs = [self.offset[id(p)] for p in params]
+        ends = [self.offset[id(p)] + (p.numel() + ALIGN - 1) // ALIGN * ALIGN for p in params]
+        return min(offs), max(ends)
+
+    def refresh_half(self, force: bool = False) -> bool:
+        """Re-cast the bf16 shadow when the fp32 parameters were modified outside the engine."""
+        v = self.flat._version
+        if force or v != self._version:
+            hip.cast_bf16(self.flat, self.half, self.total)
+            self._version = v
+            return True
+        return False
+
+    def mark_synced(self) -> None:
+        self._version = self.flat._version
+
+
+# ======================================================================================= transformer stack
+class Stack:
+    """Buffers and launch sequence for one ``Transformer`` (pre-LN blocks, fp32 residual stream, bf16 GEMMs)."""
+
+    def __init__(self, eng: "MAEEngine", holder, Bn: int, N: int, tag: str) -> None:  # noqa: N803
+        self.eng, self.t, self.Bn, self.N, self.tag = eng, holder, Bn, N, tag
+        dim, mlp = holder.dim, holder.mlp_dim
+        self.dim, self.mlp, self.H, self.Dh = dim, mlp, holder.heads, holder.dim_head
+        self.inner = self.H * self.Dh
+        self.depth = holder.depth
+        M = self.M = Bn * N  # noqa: N806
+        dev = eng.device
+        e = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
+        self.xs = [e(M, dim) for _ in range(2 * self.depth + 1)]          # residual stream, out of place
+        self.saved = []
+        for _ in range(self.depth):
+            self.saved.append(dict(
+                mean1=e(M), rstd1=e(M), mean2=e(M), rstd2=e(M), h1=e(M, dim, dt=BF16), qkv=e(M, 3 * self.inner, dt=BF16),
+                o=e(M, self.inner, dt=BF16), lse=e(Bn * self.H * N), h2=e(M, dim, dt=BF16),
+                hpre=e(M, mlp, dt=BF16), act=e(M, mlp, dt=BF16)))
+        # backward scratch (shared by all layers)
+        self.dxa, self.dxb = e(M, dim), e(M, dim)
+        self.dxa16, self.dxb16 = e(M, dim, dt=BF16), e(M, dim, dt=BF16)
+        self.dh, self.dh2 = e(M, mlp, dt=BF16), e(M, dim, dt=BF16)
+        self.do, self.dqkv, self.delta = e(M, self.inner, dt=BF16), e(M, 3 * self.inner, dt=BF16), e(Bn * self.H * N)
+
+    @property
+    def x0(self):
+        return self.xs[0]
+
+    @property
+    def x_last(self):
+        return self.xs[-1]
+
+    def forward(self) -> None:
+        eng, ps, M = self.eng, self.eng.store, self.M  # noqa: N806
+        dim, mlp, inner = self.dim, self.mlp, self.inner
+        for l, (attn, ff) in enumerate(self.t.layers):
+            s, x_in, x_mid, x_out = self.saved[l], self.xs[2 * l], self.xs[2 * l + 1], self.xs[2 * l + 2]
+            hip.layernorm_fwd(x_in, M, 0, attn.norm.weight, attn.norm.bias, s["h1"], M, 0, s["mean1"], s["rstd1"], 1, M, dim)
+            hip.gemm(hip.GEMM_NT, M, 3 * inner, dim, s["h1"], dim, ps.h(attn.to_qkv.weight), dim, s["qkv"], 3 * inner)
+            hip.attn_fwd(s["qkv"], s["o"], s["lse"], self.Bn, self.N, self.H, self.Dh, attn.scale)
+            proj = attn.to_out[0]
+            hip.gemm(hip.GEMM_NT, M, dim, inner, s["o"], inner, ps.h(proj.weight), inner, x_mid, dim,
+                     hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=proj.bias, res=x_in, ldr=dim)
+            ln2, fc1, fc2 = ff.net[0], ff.net[1], ff.net[4]
+            hip.layernorm_fwd(x_mid, M, 0, ln2.weight, ln2.bias, s["h2"], M, 0, s["mean2"], s["rstd2"], 1, M, dim)
+            hip.gemm(hip.GEMM_NT, M, mlp, dim, s["h2"], dim, ps.h(fc1.weight), dim, s["act"], mlp, hip.BIAS | hip.GELU,
+                     bias=fc1.bias, aux_out=s["hpre"], ldaux=mlp)
+            hip.gemm(hip.GEMM_NT, M, dim, mlp, s["act"], mlp, ps.h(fc2.weight), mlp, x_out, dim,
+                     hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=fc2.bias, res=x_mid, ldr=dim)
+
+    def backward(self, dx_out: torch.Tensor, dx_out16: torch.Tensor):
+        """``dx_out`` (f32) / ``dx_out16`` (bf16 copy): gradient w.r.t. ``x_last``.  Returns grad w.r.t. ``x0`` (f32)."""
+        eng, ps, M = self.eng, self.eng.store, self.M  # noqa: N806
+        dim, mlp, inner = self.dim, self.mlp, self.inner
+        AT = hip.OUT_F32 | hip.ATOMIC  # noqa: N806
+        cur, cur16 = dx_out, dx_out16
+        for l in reversed(range(self.depth)):
+            attn, ff = self.t.layers[l]
+            s, x_in, x_mid = self.saved[l], self.xs[2 * l], self.xs[2 * l + 1]
+            ln2, fc1, fc2 = ff.net[0], ff.net[1], ff.net[4]
+            mid, mid16 = (self.dxa, self.dxa16) if cur is not self.dxa else (self.dxb, self.dxb16)
+            # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
+            hip.gemm(hip.GEMM_NN, M, mlp, dim, cur16, dim, ps.h(fc2.weight), mlp, self.dh, mlp, hip.DGELU,
+                     aux_in=s["hpre"], ldaux=mlp)
+            hip.gemm(hip.GEMM_TN, dim, mlp, M, cur16, dim, s["act"], mlp, ps.g(fc2.weight), mlp, AT)
+            hip.colsum(cur16, ps.g(fc2.bias), M, dim, dim)
+            hip.gemm(hip.GEMM_NN, M, dim, mlp, self.dh, mlp, ps.h(fc1.weight), dim, self.dh2, dim)
+            hip.gemm(hip.GEMM_TN, mlp, dim, M, self.dh, mlp, s["h2"], dim, ps.g(fc1.weight), dim, AT)
+            hip.colsum(self.dh, ps.g(fc1.bias), M, mlp, mlp)
+            hip.layernorm_bwd(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16,
+                              ps.g(ln2.weight), ps.g(ln2.bias), 1, M, dim)
+            # ---- attention: x_mid = x_in + proj(attn(qkv(LN1(x_in))))
+            proj = attn.to_out[0]
+            nxt, nxt16 = (self.dxa, self.dxa16) if mid is not self.dxa else (self.dxb, self.dxb16)
+            hip.gemm(hip.GEMM_NN, M, inner, dim, mid16, dim, ps.h(proj.weight), inner, self.do, inner)
+            hip.gemm(hip.GEMM_TN, dim, inner, M, mid16, dim, s["o"], inner, ps.g(proj.weight), inner, AT)
+            hip.colsum(mid16, ps.g(proj.bias), M, dim, dim)
+            hip.attn_bwd(s["qkv"], s["o"], self.do, s["lse"], self.delta, self.dqkv, self.Bn, self.N, self.H, self.Dh,
+                         attn.scale)
+            hip.gemm(hip.GEMM_NN, M, dim, 3 * inner, self.dqkv, 3 * inner, ps.h(attn.to_qkv.weight), dim, self.dh2, dim)
+            hip.gemm(hip.GEMM_TN, 3 * inner, dim, M, self.dqkv, 3 * inner, s["h1"], dim, ps.g(attn.to_qkv.weight), dim, AT)
+            hip.layernorm_bwd(self.dh2, M, 0, x_in, M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid, nxt, nxt16,
+                              ps.g(attn.norm.weight), ps.g(attn.norm.bias), 1, M, dim)
+            cur, cur16 = nxt, nxt16
+            eng._grads_ready(self.t.layers[l])
+        return cur
+
+
+# ======================================================================================= the engine
+class MAEEngine:
+    def __init__(self, model, batch_size: int, device, loss: str = "l2_norm") -> None:
+        if loss not in ("l1", "l2", "l1_norm", "l2_norm"):
+            raise ValueError(f"Invalid loss {loss}.")
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise hip.HipExtensionError("MAEEngine needs a GPU device; the MAE hot path has no CPU fallback")
+        hip.lib()  # fail loudly now if the extension is missing
+        self.model, self.B, self.device, self.loss = model, batch_size, device, loss
+        self.p_loss = 1 if loss.startswith("l1") else 2
+        self.normalise = loss.endswith("_norm")
+        m = model
+        if m.embed_dim == m.decoder_dim:
+            raise NotImplementedError("embed_dim == decoder_dim (Identity enc_to_dec) is not built")
+        self.E, self.Dd = m.embed_dim, m.decoder_dim
+        self.grad_hook = None  # callable(lo, hi) invoked when grad[lo:hi] is final (DDP bucket launch)
+        B = batch_size  # noqa: N806
+        fold = m.fusion_mode in ("shared", "monotemp")
+        self.mods, self.groups = m.mod_specs, list(m.group_specs.values())
+        for s in self.mods.values():
+            s.Beff = B * s.Dates if fold else B
+        for g in self.groups:
+            g.Beff = g.mods[0].Beff
+        # ---- flat parameter store; order = forward order so that backward finishes contiguous tail slices first
+        ordered = []
+        for name in m.patch_embed:
+            ordered += [(f"patch_embed.{name}.{k}", p) for k, p in m.patch_embed[name].named_parameters()]
+        for name in m.encoder:
+            ordered += [(f"encoder.{name}.{k}", p) for k, p in m.encoder[name].named_parameters()]
+        if m.encoder_inter is not None:
+            ordered += [(f"encoder_inter.{k}", p) for k, p in m.encoder_inter.named_parameters()]
+        for name in m.enc_to_dec:
+            ordered += [(f"enc_to_dec.{name}.{k}", p) for k, p in m.enc_to_dec[name].named_parameters()]
+        ordered += [(f"mask_token.{k}", p) for k, p in m.mask_token.items()]
+        for name in m.decoder:
+            ordered += [(f"decoder.{name}.{k}", p) for k, p in m.decoder[name].named_parameters()]
+        for name in m.embed_to_rec:
+            ordered += [(f"embed_to_rec.{name}.{k}", p) for k, p in m.embed_to_rec[name].named_parameters()]
+        self.store = ParamStore(ordered, device)
+        for bname in ("enc_pos_encoding", "dec_pos_encoding"):
+            setattr(m, bname, getattr(m, bname).to(device))
+        self._alloc()
+        self.store.refresh_half(force=True)
+        self._pack_conv_weights()
+        self.step_count = 0
+
+    # ------------------------------------------------------------------------------------------ allocation
+    def _alloc(self) -> None:
+        m, dev, E, Dd = self.model, self.device, self.E, self.Dd  # noqa: N806
+        e = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
+        z = lambda *s, dt=F32: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        self.mb = {}
+        for name, s in self.mods.items():
+            T = s.Beff * s.n_tok  # noqa: N806
+            BD = s.Beff * s.D  # noqa: N806
+            pe = m.patch_embed[s.embed].patchify_bands[0]
+            self.mb[name] = dict(
+                cols=e(T, s.Kpad, dt=BF16), target=e(T, s.K), yconv=e(T, E),
+                gn_partial=e(hip.groupnorm_partial_size(BD, s.L, E)), gn_stats=e(BD, 2), gn_sums=e(BD, 2),
+                pos_enc=m.pos_enc_rows[name].to(dev), norm_bands=torch.tensor(s.norm_bands, dtype=I32, device=dev),
+                w_conv16=z(E, s.Kpad, dt=BF16), dw_conv=z(E, s.Kpad), dyc=e(T, E, dt=BF16),
+                hdec=e(T, Dd, dt=BF16), mean_f=e(T), rstd_f=e(T), rec=e(T, s.K), drec=e(T, s.K, dt=BF16),
+                dh=e(T, Dd, dt=BF16), cnt=z(1, dt=I32), pe=pe)
+        self.gb = {}
+        self.enc, self.dec = {}, {}
+        for g in self.groups:
+            Bn, L, N = g.Beff, g.L, g.N  # noqa: N806
+            n_dates = sum(s.D for s in g.mods)
+            tok_slot = torch.cat([torch.full((s.n_tok,), s.slot, dtype=I32) for s in g.mods])
+            date_row = torch.cat([(s.date_off + torch.arange(s.n_tok) // s.L).to(I32) for s in g.mods])
+            pos_dec = torch.cat([m.pos_dec_rows[s.name].repeat(s.D, 1) for s in g.mods], dim=0)
+            self.gb[g.name] = dict(
+                xg=e(Bn, L, E), dxg=z(Bn, L, E), noise_h=torch.empty(Bn, L, dtype=F32).pin_memory(),
+                struct_h=torch.empty(Bn, L, dtype=U8).pin_memory(), noise=e(Bn, L), struct=e(Bn, L, dt=U8),
+                vis=e(Bn, N, dt=I32), msk=e(Bn, g.k, dt=I32), inv=e(Bn, L, dt=I32), mask=e(Bn, L, dt=U8),
+                dates=z(Bn, n_dates, 8), n_dates=n_dates, tok_slot=tok_slot.to(dev), date_row=date_row.to(dev),
+                pos_dec=pos_dec.to(dev).contiguous(), tok_table=e(len(g.mods), Dd),
+                henc=e(Bn * N, E, dt=BF16), mean_e=e(Bn * N), rstd_e=e(Bn * N), y_e2d=e(Bn * N, Dd),
+                dy_e2d=e(Bn * N, Dd), dy_e2d16=e(Bn * N, Dd, dt=BF16), dhenc=e(Bn * N, E, dt=BF16),
+                mean_j=e(Bn * N), rstd_j=e(Bn * N))
+            holder = m.encoder[g.model]
+            self.enc[g.name] = Stack(self, holder, Bn, N, f"enc.{g.name}")
+            self.dec[g.name] = Stack(self, m.decoder[g.model], Bn, L, f"dec.{g.name}")
+        if m.encoder_inter is not None:
+            self.joint = Stack(self, m.encoder_inter, self.B, m.joint_N, "joint")
+        else:
+            self.joint = None
+        self.loss_acc = z(1)
+        tot_w = sum(s.Dates * s.L for s in self.mods.values())
+        self.loss_w = {n: (s.Dates * s.L) / tot_w for n, s in self.mods.items()}  # weight = D*H*W (model.py:239)
+
+    def _pack_conv_weights(self) -> None:
+        for name, s in self.mods.items():
+            b = self.mb[name]
+            hip.pack_rows_bf16(b["pe"].conv.weight, b["w_conv16"], self.E, s.K, s.Kpad)
+
+    def _grads_ready(self, module) -> None:
+        if self.grad_hook is not None:
+            ps = list(module.parameters())
+            if ps:
+                self.grad_hook(*self.store.span(ps))
+
+    # ------------------------------------------------------------------------------------------ RNG (host)
+    def draw_masks(self, generator=None):
+        """Host draws in the reference's order: structural masks first, then ``rand(B, L)`` per group."""
+        struct = draw_struct_masks(self.groups, self.mods, generator)
+        noise = {g.name: torch.rand((g.Beff, g.L), generator=generator) for g in self.groups}
+        return noise, struct
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, batch: dict, noise: dict | None = None, struct: dict | None = None) -> torch.Tensor:
+        """Runs the forward pass + loss; returns the loss as a 1-element device tensor (no host sync)."""
+        m, E, Dd = self.model, self.E, self.Dd  # noqa: N806
+        if self.store.refresh_half():
+            self._pack_conv_weights()
+        if noise is None or struct is None:
+            n2, s2 = self.draw_masks()
+            noise = noise if noise is not None else n2
+            struct = struct if struct is not None else s2
+        self.loss_acc.zero_()
+        ref_date = batch["ref_date"]
+        # ---- embed: patchify -> conv GEMM -> GroupNorm + encodings into the group sequence
+        for g in self.groups:
+            gbuf = self.gb[g.name]
+            for s in g.mods:
+                b = self.mb[s.name]
+                img = batch[s.name]
+                if tuple(img.shape[-2:]) != (s.S, s.S):
+                    raise NotImplementedError("input rasters must already be at image_size (resize: SURVEY §8(f) next)")
+                if img.dtype != F32 or not img.is_contiguous():
+                    raise ValueError(f"batch[{s.name!r}] must be a contiguous float32 tensor")
+                BD = s.Beff * s.D  # noqa: N806
+                hip.patchify(img, b["cols"], b["target"], BD, s.C, s.S, s.P, s.Kpad, b["norm_bands"], len(s.norm_bands),
+                             self.normalise, s.rescale_elev)
+                dates = batch[f"{s.name}_dates"]
+                fold = s.D != s.Dates
+                if fold:   # dates folded into the batch: one date row per sequence
+                    hip.date_features(dates, ref_date, gbuf["dates"].view(self.B, s.Dates, 8), self.B, s.Dates, s.Dates, 0,
+                                      m.fac_date_enc)
+                else:
+                    hip.date_features(dates, ref_date, gbuf["dates"], self.B, s.D, gbuf["n_dates"], s.date_off, m.fac_date_enc)
+                pe = b["pe"]
+                T = s.Beff * s.n_tok  # noqa: N806
+                hip.gemm(hip.GEMM_NT, T, E, s.Kpad, b["cols"], s.Kpad, b["w_conv16"], s.Kpad, b["yconv"], E,
+                         hip.OUT_F32 | hip.BIAS, bias=pe.conv.bias)
+                hip.groupnorm_stats(b["yconv"], b["gn_partial"], b["gn_stats"], BD, s.L, E)
+                hip.embed_finish(b["yconv"], b["gn_stats"], pe.norm.weight, pe.norm.bias, b["pos_enc"], gbuf["dates"],
+                                 gbuf["n_dates"], s.date_off, gbuf["xg"], s.Beff, s.D, s.L, E, s.tok_off, g.L)
+        # ---- mask + gather + per-group encoder
+        for g in self.groups:
+            gbuf, st = self.gb[g.name], self.enc[g.name]
+            gbuf["noise_h"].copy_(noise[g.name])
+            gbuf["struct_h"].copy_(struct[g.name].reshape(g.Beff, g.L).to(U8))
+            gbuf["noise"].copy_(gbuf["noise_h"], non_blocking=True)
+            gbuf["struct"].copy_(gbuf["struct_h"], non_blocking=True)
+            hip.mask_select(gbuf["noise"], gbuf["struct"], gbuf["vis"], gbuf["msk"], gbuf["inv"], gbuf["mask"], g.Beff, g.L, g.k)
+            hip.gather_rows(gbuf["xg"], gbuf["vis"], st.x0, g.Beff, g.L, g.N, E, g.N, 0)
+            st.forward()
+        # ---- joint encoder over the concatenated visible tokens, then final LN per group -> bf16
+        for g in self.groups:
+            gbuf, st = self.gb[g.name], self.enc[g.name]
+            nrm = st.t.norm
+            if self.joint is not None:
+                hip.layernorm_fwd(st.x_last, g.N, 0, nrm.weight, nrm.bias, self.joint.x0, m.joint_N, g.joint_off,
+                                  gbuf["mean_e"], gbuf["rstd_e"], g.Beff, g.N, E)
+            else:
+                hip.layernorm_fwd(st.x_last, g.N, 0, nrm.weight, nrm.bias, gbuf["henc"], g.N, 0, gbuf["mean_e"],
+                                  gbuf["rstd_e"], g.Beff, g.N, E)
+        if self.joint is not None:
+            self.joint.forward()
+            nrm = self.joint.t.norm
+            for g in self.groups:
+                gbuf = self.gb[g.name]
+                hip.layernorm_fwd(self.joint.x_last, m.joint_N, g.joint_off, nrm.weight, nrm.bias, gbuf["henc"], g.N, 0,
+                                  gbuf["mean_j"], gbuf["rstd_j"], g.Beff, g.N, E)
+        # ---- enc_to_dec, unmask + decoder encodings, decoder, pixelify, loss
+        for g in self.groups:
+            gbuf, st = self.gb[g.name], self.dec[g.name]
+            lin = m.enc_to_dec[g.model]
+            M = g.Beff * g.N  # noqa: N806
+            hip.gemm(hip.GEMM_NT, M, Dd, E, gbuf["henc"], E, self.store.h(lin.weight), E, gbuf["y_e2d"], Dd,
+                     hip.OUT_F32 | hip.BIAS, bias=lin.bias)
+            for s in g.mods:
+                gbuf["tok_table"][s.slot].copy_(m.mask_token[s.name].view(-1))
+            hip.unmask_assemble(gbuf["y_e2d"], gbuf["inv"], gbuf["tok_table"], gbuf["tok_slot"], gbuf["pos_dec"],
+                                gbuf["dates"], gbuf["date_row"], gbuf["n_dates"], st.x0, g.Beff, g.L, g.N, Dd)
+            st.forward()
+            nrm = st.t.norm
+            for s in g.mods:
+                b = self.mb[s.name]
+                T = s.Beff * s.n_tok  # noqa: N806
+                conv = m.embed_to_rec[s.embed].pixelify_bands[0].conv
+                hip.layernorm_fwd(st.x_last, g.L, s.tok_off, nrm.weight, nrm.bias, b["hdec"], s.n_tok, 0, b["mean_f"],
+                                  b["rstd_f"], s.Beff, s.n_tok, Dd)
+                hip.gemm(hip.GEMM_NT, T, s.K, Dd, b["hdec"], Dd, self.store.h(conv.weight).view(s.K, Dd), Dd, b["rec"], s.K,
+                         hip.OUT_F32 | hip.BIAS, bias=conv.bias)
+                hip.count_masked(gbuf["mask"], g.Beff, g.L, s.tok_off, s.tok_off + s.n_tok, b["cnt"])
+                hip.masked_loss(b["rec"], b["target"], gbuf["mask"], b["cnt"], self.loss_w[s.name], self.loss_acc, b["drec"],
+                                s.Beff, s.n_tok, g.L, s.tok_off, s.K, self.p_loss)
+        return self.loss_acc
+
+    # ------------------------------------------------------------------------------------------ backward
+    def zero_grad(self) -> None:
+        self.store.grad.zero_()
+
+    def backward(self, grad_scale: float = 1.0) -> None:
+        """Backward of the last ``forward`` (d loss = 1); accumulates into the flat grad buffer (zero it first)."""
+        if grad_scale != 1.0:
+            raise NotImplementedError("loss scaling is not needed for bf16 (SURVEY §8(f) AMP row)")
+        m, E, Dd, ps = self.model, self.E, self.Dd, self.store  # noqa: N806
+        AT = hip.OUT_F32 | hip.ATOMIC  # noqa: N806
+        for g in reversed(self.groups):
+            gbuf, st = self.gb[g.name], self.dec[g.name]
+            nrm = st.t.norm
+            dx, dx16 = st.dxa, st.dxa16          # gradient w.r.t. the decoder's last residual
+            for s in g.mods:
+                b = self.mb[s.name]
+                T = s.Beff * s.n_tok  # noqa: N806
+                conv = m.embed_to_rec[s.embed].pixelify_bands[0].conv
+                w16 = ps.h(conv.weight).view(s.K, Dd)
+                hip.gemm(hip.GEMM_NN, T, Dd, s.K, b["drec"], s.K, w16, Dd, b["dh"], Dd)
+                hip.gemm(hip.GEMM_TN, s.K, Dd, T, b["drec"], s.K, b["hdec"], Dd, ps.g(conv.weight).view(s.K, Dd), Dd, AT)
+                hip.colsum(b["drec"], ps.g(conv.bias), T, s.K, s.K)
+                hip.layernorm_bwd(b["dh"], s.n_tok, 0, st.x_last, g.L, s.tok_off, nrm.weight, b["mean_f"], b["rstd_f"], None,
+                                  dx, dx16, ps.g(nrm.weight), ps.g(nrm.bias), s.Beff, s.n_tok, Dd)
+                self._grads_ready(m.embed_to_rec[s.embed])
+            dx0 = st.backward(dx, dx16)
+            self._grads_ready(nrm)
+            # unmask backward: visible rows -> enc_to_dec output grad; masked rows -> mask-token grads
+            hip.gather_rows(dx0, gbuf["vis"], gbuf["dy_e2d"], g.Beff, g.L, g.N, Dd, g.N, 0)
+            for s in g.mods:
+                hip.unmask_token_grad(dx0, gbuf["mask"], gbuf["tok_slot"], ps.g(m.mask_token[s.name]).view(-1), g.Beff, g.L,
+                                      Dd, s.slot, s.tok_off, s.tok_off + s.n_tok)
+            M = g.Beff * g.N  # noqa: N806
+            hip.cast_bf16(gbuf["dy_e2d"], gbuf["dy_e2d16"], M * Dd)
+            lin = m.enc_to_dec[g.model]
+            hip.gemm(hip.GEMM_NN, M, E, Dd, gbuf["dy_e2d16"], Dd, ps.h(lin.weight), E, gbuf["dhenc"], E)
+            hip.gemm(hip.GEMM_TN, Dd, E, M, gbuf["dy_e2d16"], Dd, gbuf["henc"], E, ps.g(lin.weight), E, AT)
+            hip.colsum(gbuf["dy_e2d16"], ps.g(lin.bias), M, Dd, Dd)
+            self._grads_ready(lin)
+        # ---- joint encoder
+        if self.joint is not None:
+            jt = self.joint
+            nrm = jt.t.norm
+            for g in self.groups:
+                gbuf = self.gb[g.name]
+                hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, jt.x_last, m.joint_N, g.joint_off, nrm.weight, gbuf["mean_j"],
+                                  gbuf["rstd_j"], None, jt.dxa, jt.dxa16, ps.g(nrm.weight), ps.g(nrm.bias), g.Beff, g.N, E)
+            djoint = jt.backward(jt.dxa, jt.dxa16)
+            self._grads_ready(nrm)
+        for g in reversed(self.groups):
+            gbuf, st = self.gb[g.name], self.enc[g.name]
+            nrm = st.t.norm
+            if self.joint is not None:
+                hip.layernorm_bwd(djoint, m.joint_N, g.joint_off, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"],
+                                  gbuf["rstd_e"], None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias), g.Beff, g.N, E)
+            else:
+                hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"], gbuf["rstd_e"],
+                                  None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias), g.Beff, g.N, E)
+            dx0 = st.backward(st.dxa, st.dxa16)
+            self._grads_ready(nrm)
+            # scatter to the full group sequence (masked tokens get zero), then patch-embed backward per modality
+            gbuf["dxg"].zero_()
+            hip.scatter_rows(dx0, gbuf["vis"], gbuf["dxg"], g.Beff, g.L, g.N, E, g.N, 0)
+            for s in g.mods:
+                b = self.mb[s.name]
+                pe = b["pe"]
+                T = s.Beff * s.n_tok  # noqa: N806
+                hip.embed_finish_bwd(gbuf["dxg"], b["yconv"], b["gn_stats"], pe.norm.weight, b["dyc"], ps.g(pe.norm.weight),
+                                     ps.g(pe.norm.bias), b["gn_sums"], s.Beff, s.D, s.L, E, s.tok_off, g.L)
+                b["dw_conv"].zero_()
+                hip.gemm(hip.GEMM_TN, E, s.Kpad, T, b["dyc"], E, b["cols"], s.Kpad, b["dw_conv"], s.Kpad, AT)
+                hip.unpack_rows_add(b["dw_conv"], ps.g(pe.conv.weight), E, s.K, s.Kpad)
+                hip.colsum(b["dyc"], ps.g(pe.conv.bias), T, E, E)
+        for name in m.patch_embed:
+            self._grads_ready(m.patch_embed[name])
+
+    # ------------------------------------------------------------------------------------------ outputs
+    def reconstructions(self):
+        """``pixels_rec`` / ``mask_rec`` in the reference's image layout ``[B, D, C, S, S]`` (materialised lazily)."""
+        pixels, masks = {}, {}
+        for g in self.groups:
+            mask = self.gb[g.name]["mask"]
+            for s in g.mods:
+                b = self.mb[s.name]
+                BD = s.Beff * s.D  # noqa: N806
+                img = torch.empty(BD, s.C, s.S, s.S, dtype=F32, device=self.device)
+                hip.depatchify(b["rec"], img, BD, s.C, s.S, s.P)
+                pixels[s.name] = img.view(self.B, s.Dates, s.C, s.S, s.S)
+                tok = mask[:, s.tok_off: s.tok_off + s.n_tok].bool().reshape(self.B, s.Dates, 1, s.g, 1, s.g, 1)
+                masks[s.name] = tok.expand(self.B, s.Dates, s.C, s.g, s.P, s.g, s.P).reshape(self.B, s.Dates, s.C, s.S, s.S)
+        return pixels, masks
+
+    def returned_batch(self, batch: dict) -> dict:
+        """The reference returns the (in place) resized / elevation-rescaled batch (mim.py:425-437)."""
+        out = dict(batch)
+        for s in self.mods.values():
+            if s.rescale_elev:
+                img = batch[s.name]
+                res = torch.empty_like(img)
+                hip.rescale_elev(img, res, img.shape[0] * img.shape[1], s.C, s.S)
+                out[s.name] = res
+        return out
+
+    def token_masks(self) -> dict:
+        """Per-group token masks ``{group: bool [Beff, L]}`` of the last forward."""
+        return {g.name: self.gb[g.name]["mask"].bool() for g in self.groups}

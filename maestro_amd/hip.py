@@ -106,8 +106,17 @@ def groupnorm_stats(y, partial, stats, BD, L, E, eps=1e-5):
     call("mh_groupnorm_stats", y, partial, stats, _I(BD), _I(L), _I(E), _F(eps))
 
 
-def embed_finish(y, stats, gamma, beta, pos, date, xg, B, D, L, E, tok_off, Lgroup):
-    call("mh_embed_finish", y, stats, gamma, beta, pos, date, xg, _I(B), _I(D), _I(L), _I(E), _I(tok_off), _I(Lgroup))
+def embed_finish(y, stats, gamma, beta, pos, date, date_rows, date_off, xg, B, D, L, E, tok_off, Lgroup):
+    call("mh_embed_finish", y, stats, gamma, beta, pos, date, _I(date_rows), _I(date_off), xg, _I(B), _I(D), _I(L), _I(E),
+         _I(tok_off), _I(Lgroup))
+
+
+def date_features(dates, ref_date, out, B, D, rows, row_off, fac):
+    call("mh_date_features", dates, ref_date, out, _I(B), _I(D), _I(rows), _I(row_off), _F(fac))
+
+
+def rescale_elev(img, out, BD, C, S):
+    call("mh_rescale_elev", img, out, _I(BD), _I(C), _I(S))
 
 
 def embed_finish_bwd(dxg, y, stats, gamma, dyc, dgamma, dbeta, sums, B, D, L, E, tok_off, Lgroup):

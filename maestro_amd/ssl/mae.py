@@ -1,0 +1,240 @@
+"""MI355X-native MAE: same constructor / factories / forward contract as ``maestro.ssl.mae`` + ``maestro.ssl.mim``.
+
+* constructor and ``mae_{tiny,small,medium,large}`` factories  -> reference ``maestro/ssl/mae.py:18-176,309-378``
+* module tree / state-dict keys (``patch_embed``, ``embed_to_rec``, ``mask_token``, ``encoder``, ``enc_to_dec``,
+  ``decoder``, ``encoder_inter``, ``heads``)                   -> ``maestro/ssl/mim.py:59-197``, ``mae.py:133-176``
+* ``forward(batch, ssl_phase) -> (batch, pixels_rec, mask_rec, logits)`` -> ``maestro/ssl/mim.py:473-505``
+
+The modules only hold parameters; all per-step arithmetic runs in :class:`maestro_amd.engine.MAEEngine`
+(hand-written HIP kernels through the C ABI).  There is no PyTorch/CPU fallback: without a GPU and the built
+extension ``forward`` raises.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from functools import reduce
+from math import gcd
+
+import torch
+from torch import nn
+
+from maestro_amd.layers.embed import Patchify, Pixelify
+from maestro_amd.layers.utils import pool_pos_table, posemb_sincos_2d
+from maestro_amd.layers.vit import Transformer
+
+
+@dataclass
+class ModSpec:
+    """Geometry of one input modality as the engine sees it."""
+
+    name: str
+    embed: str            # key in patch_embed / embed_to_rec (name_embed sharing, mim.py:62-69)
+    group: str
+    C: int                # bands
+    S: int                # image size
+    P: int                # patch size
+    g: int                # grid
+    L: int                # tokens per date = g*g
+    D: int                # dates inside one sequence (1 when dates are folded into the batch)
+    Dates: int            # true number of dates of the modality
+    Beff: int = 0         # sequences per step (B, or B*Dates for shared/monotemp); set by the engine
+    tok_off: int = 0      # first token of this modality inside its group sequence
+    date_off: int = 0     # first row of this modality in the group's date table
+    slot: int = 0         # row of this modality in the group's mask-token table
+    norm_bands: tuple = ()
+    rescale_elev: bool = False
+    p_mod: float | None = None
+    p_bands: float | None = None
+    p_dates: float | None = None
+    p_loc: float | None = None
+
+    @property
+    def K(self) -> int:  # noqa: N802
+        return self.C * self.P * self.P
+
+    @property
+    def Kpad(self) -> int:  # noqa: N802
+        return (self.K + 31) // 32 * 32
+
+    @property
+    def n_tok(self) -> int:
+        return self.D * self.L
+
+
+@dataclass
+class GroupSpec:
+    name: str
+    model: str            # key into encoder / enc_to_dec / decoder ("shared" fallback, mim.py:403)
+    mods: list = field(default_factory=list)
+    L: int = 0
+    k: int = 0            # masked tokens (banker's rounding, mae.py:244-246)
+    ratio: float = 0.75
+    Beff: int = 0
+    joint_off: int = 0
+
+    @property
+    def N(self) -> int:  # noqa: N802
+        return self.L - self.k
+
+
+class MAE(nn.Module):
+    """Masked Auto Encoder (multi-modal, multi-temporal)."""
+
+    def __init__(self, datasets, mask, interpolate, fusion_mode, inter_depth, model, num_levels, embed_dim, depth,
+                 heads, dim_head, mlp_ratio, decoder_dim, decoder_depth, decoder_heads, decoder_dim_head,
+                 decoder_mlp_ratio, type_head="attentive", fac_abs_enc=1.0, fac_date_enc=1.0, date_dim=8,
+                 **kwargs) -> None:  # noqa: ARG002
+        super().__init__()
+        if num_levels != 1:
+            raise NotImplementedError("num_levels != 1 is not supported (reference: Literal[1])")
+        if fusion_mode not in ("shared", "monotemp", "mod", "group"):
+            raise ValueError(f"Invalid fusion mode {fusion_mode}.")
+        ds = self.dataset = datasets.dataset
+        self.stride = 1
+        self.interpolate, self.fusion_mode, self.inter_depth = interpolate, fusion_mode, inter_depth
+        self.embed_dim, self.decoder_dim, self.date_dim = embed_dim, decoder_dim, date_dim
+        self.depth, self.heads, self.dim_head, self.mlp_dim = depth, heads, dim_head, int(embed_dim * mlp_ratio)
+        self.decoder_depth, self.decoder_heads, self.decoder_dim_head = decoder_depth, decoder_heads, decoder_dim_head
+        self.decoder_mlp_dim = int(embed_dim * decoder_mlp_ratio)  # sic: embed_dim (mae.py:162)
+        self.fac_abs_enc, self.fac_date_enc = fac_abs_enc, fac_date_enc
+
+        self.num_bands = {m: ([c.bands] if isinstance(c.bands, int) else [len(b) for b in c.bands])
+                          for m, c in ds.inputs.items()}
+        self.len_bands = {m: len(nb) for m, nb in self.num_bands.items()}
+        self.mod_embed, self.grid_size, self.out_grid_size = {}, {}, {}
+        self.patch_embed, self.embed_to_rec = nn.ModuleDict(), nn.ModuleDict()
+        for m, c in ds.inputs.items():
+            e = c.name_embed if c.name_embed else m
+            self.mod_embed[m] = e
+            self.grid_size[m] = self.out_grid_size[m] = c.image_size // c.patch_size.mae
+            if e in self.patch_embed:
+                continue
+            self.patch_embed[e] = Patchify(c.bands, embed_dim, c.patch_size.mae)
+            self.embed_to_rec[e] = Pixelify(decoder_dim, c.bands, c.patch_size.mae)
+
+        G = ds.grid_pos_enc if ds.grid_pos_enc is not None else reduce(  # noqa: N806
+            lambda a, b: a * b // gcd(a, b), self.grid_size.values())
+        self.register_buffer("enc_pos_encoding", posemb_sincos_2d(G, G, embed_dim, date_dim) * fac_abs_enc,
+                             persistent=False)
+        self.register_buffer("dec_pos_encoding", posemb_sincos_2d(G, G, decoder_dim, date_dim), persistent=False)
+
+        self.mask_token = nn.ParameterDict(
+            {m: nn.Parameter(torch.randn(1, lb, 1, 1, decoder_dim)) for m, lb in self.len_bands.items()})
+        self.heads = nn.ModuleDict()  # probe / finetune heads: SURVEY §8(f) "next" row, not on the pretrain path
+
+        # ---- masking probabilities per fusion mode (mae.py:60-131)
+        nd_mod, nd_group = {}, {}
+        for m, g in ds.groups:
+            nd = ds.inputs[m].num_dates * self.len_bands[m]
+            nd_mod[m] = nd_mod.get(m, 0) + nd
+            nd_group[g] = nd_group.get(g, 0) + nd
+        self.mask_ratio, self.mask_mod, self.mask_bands, self.mask_dates, self.mask_loc = {}, {}, {}, {}, {}
+        if fusion_mode in ("shared", "monotemp"):
+            name_models = list(nd_mod) if fusion_mode == "monotemp" else ["shared"]
+            for m in nd_mod:
+                self.mask_ratio[m] = mask.mask_ratio
+                self.mask_mod[m] = self.mask_bands[m] = self.mask_dates[m] = self.mask_loc[m] = None
+        else:
+            name_models = list(nd_group) if fusion_mode == "group" else list(nd_mod)
+            for m, g in ds.groups:
+                if fusion_mode == "group":
+                    self.mask_ratio[g] = 1 - (1 - mask.mask_ratio) / nd_group[g] ** mask.mask_scale
+                    self.mask_mod[m] = mask.mask_mod if nd_mod[m] != nd_group[g] else None
+                else:
+                    self.mask_ratio[m] = 1 - (1 - mask.mask_ratio) / nd_mod[m] ** mask.mask_scale
+                    self.mask_mod[m] = None
+                self.mask_bands[m] = mask.mask_bands if self.len_bands[m] > 1 else None
+                self.mask_dates[m] = mask.mask_dates if ds.inputs[m].num_dates > 1 else None
+                self.mask_loc[m] = mask.mask_loc
+
+        self.encoder = nn.ModuleDict({n: Transformer(embed_dim, depth - inter_depth, heads, dim_head, self.mlp_dim)
+                                      for n in name_models})
+        self.enc_to_dec = nn.ModuleDict({n: (nn.Linear(embed_dim, decoder_dim) if embed_dim != decoder_dim
+                                             else nn.Identity()) for n in name_models})
+        self.decoder = nn.ModuleDict({n: Transformer(decoder_dim, decoder_depth, decoder_heads, decoder_dim_head,
+                                                     self.decoder_mlp_dim) for n in name_models})
+        self.encoder_inter = (Transformer(embed_dim, inter_depth, heads, dim_head, self.mlp_dim)
+                              if inter_depth else None)
+        self._engine = None
+        self._build_specs()
+
+    # ------------------------------------------------------------------------------------------ geometry
+    def _build_specs(self) -> None:
+        ds = self.dataset
+        fold = self.fusion_mode in ("shared", "monotemp")  # dates folded into the batch (utils.py:26-37)
+        group_of = {m: (g if self.fusion_mode == "group" else m) for m, g in ds.groups}
+        self.mod_specs: dict[str, ModSpec] = {}
+        self.group_specs: dict[str, GroupSpec] = {}
+        for m, c in ds.inputs.items():
+            if self.len_bands[m] != 1:
+                raise NotImplementedError(
+                    f"modality {m}: several band-groups (len_bands={self.len_bands[m]}) are not supported by the HIP "
+                    "engine yet (unused by every shipped dataset config, SURVEY Q18)")
+            gname = group_of[m]
+            g = self.grid_size[m]
+            nb = tuple(c.norm_bands) if c.norm_bands is not None else tuple(self.num_bands[m])
+            spec = ModSpec(name=m, embed=self.mod_embed[m], group=gname, C=sum(self.num_bands[m]), S=c.image_size,
+                           P=c.patch_size.mae, g=g, L=g * g, D=1 if fold else c.num_dates, Dates=c.num_dates,
+                           norm_bands=nb, rescale_elev=bool(c.rescale_elev), p_mod=self.mask_mod[m],
+                           p_bands=self.mask_bands[m], p_dates=self.mask_dates[m], p_loc=self.mask_loc[m])
+            if gname not in self.group_specs:
+                model_key = gname if gname in self.encoder else "shared"
+                self.group_specs[gname] = GroupSpec(name=gname, model=model_key, ratio=self.mask_ratio[gname])
+            grp = self.group_specs[gname]
+            spec.tok_off, spec.date_off, spec.slot = grp.L, sum(x.D for x in grp.mods), len(grp.mods)
+            grp.mods.append(spec)
+            grp.L += spec.n_tok
+            self.mod_specs[m] = spec
+        off = 0
+        for grp in self.group_specs.values():
+            grp.k = round(grp.ratio * grp.L)  # Python banker's rounding, as the reference
+            grp.joint_off = off
+            off += grp.N
+        self.joint_N = off
+        # constant positional rows per modality (enc: [L, E]; dec: [L, Dd]); built once
+        self.pos_enc_rows = {m: pool_pos_table(self.enc_pos_encoding.cpu(), s.g) for m, s in self.mod_specs.items()}
+        self.pos_dec_rows = {m: pool_pos_table(self.dec_pos_encoding.cpu(), s.g) for m, s in self.mod_specs.items()}
+
+    # ------------------------------------------------------------------------------------------ engine plumbing
+    def engine(self, batch_size: int, device=None, loss: str = "l2_norm"):
+        """Return (building on first use / batch-size change) the HIP step engine bound to these parameters."""
+        from maestro_amd.engine import MAEEngine
+
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        if self._engine is None or self._engine.B != batch_size or self._engine.loss != loss \
+                or self._engine.device != device:
+            self._engine = MAEEngine(self, batch_size, device, loss=loss)
+        return self._engine
+
+    def forward(self, batch: dict, ssl_phase: str = "pretrain"):
+        """Reference contract ``(batch, pixels_rec, mask_rec, logits)``; pretrain branch only."""
+        if ssl_phase != "pretrain":
+            raise NotImplementedError("probe/finetune branch is a SURVEY §8(f) 'next' row; only pretrain is built")
+        first = next(iter(self.dataset.inputs))
+        eng = self.engine(batch[first].shape[0], batch[first].device)
+        eng.forward(batch)
+        pixels_rec, mask_rec = eng.reconstructions()
+        return eng.returned_batch(batch), pixels_rec, mask_rec, None
+
+
+_SIZES = {
+    "tiny": dict(embed_dim=192, depth=12, heads=3, dim_head=64, mlp_ratio=2, decoder_depth=1),
+    "small": dict(embed_dim=384, depth=12, heads=6, dim_head=64, mlp_ratio=2, decoder_depth=2),
+    "medium": dict(embed_dim=768, depth=12, heads=12, dim_head=64, mlp_ratio=4, decoder_depth=3),
+    "large": dict(embed_dim=1024, depth=24, heads=16, dim_head=64, mlp_ratio=4, decoder_depth=4),
+}
+
+
+def _factory(size: str):
+    def build(**kwargs) -> MAE:
+        args = dict(_SIZES[size], decoder_dim=512, decoder_heads=16, decoder_dim_head=32, decoder_mlp_ratio=4)
+        args.update(kwargs)
+        return MAE(**args)
+
+    build.__name__ = f"mae_{size}"
+    build.__doc__ = f"Construct MAE {size} (reference maestro/ssl/mae.py:309-378)."
+    return build
+
+
+mae_tiny, mae_small, mae_medium, mae_large = (_factory(s) for s in ("tiny", "small", "medium", "large"))

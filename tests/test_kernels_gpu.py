@@ -141,7 +141,7 @@ def test_groupnorm_embed_finish_fwd_bwd(dev, B, D, L, E, tok_off, Lg):
     stats = torch.zeros(B * D, 2, device=dev)
     hip.groupnorm_stats(y, partial, stats, B * D, L, E)
     xg = torch.full((B, Lg, E), 5.0, device=dev)
-    hip.embed_finish(y, stats, gamma, beta, pos, date, xg, B, D, L, E, tok_off, Lg)
+    hip.embed_finish(y, stats, gamma, beta, pos, date, D, 0, xg, B, D, L, E, tok_off, Lg)
     yr = y.clone().requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     img = yr.reshape(B * D, L, E)
@@ -165,6 +165,24 @@ def test_groupnorm_embed_finish_fwd_bwd(dev, B, D, L, E, tok_off, Lg):
     assert (dyc.float() - yr.grad).abs().max() < 2e-2 * scale
     assert (dg - gr.grad).abs().max() < 1e-3 * max(1, gr.grad.abs().max().item())
     assert (db - br.grad).abs().max() < 1e-3 * max(1, br.grad.abs().max().item())
+
+
+def test_date_features_and_rescale(dev):
+    from maestro_amd import hip
+    from oracle import layers as ol
+    dates = torch.tensor([[[2019, 100, 10], [2020, 3, 23], [2018, 365, 0]],
+                          [[2021, 200, 12], [2019, 182, 0], [2017, 1, 5]]], dtype=torch.int16)
+    ref = torch.tensor([[[2019, 182, 0]], [[2020, 1, 0]]], dtype=torch.int16)
+    out = torch.zeros(2, 5, 8, device=dev)
+    hip.date_features(dates.to(dev), ref.to(dev), out, 2, 3, 5, 2, 0.5)
+    want = ol.date_features(dates, ref, 0.5)
+    assert (out[:, 2:].cpu() - want).abs().max() < 2e-6 and (out[:, :2] == 0).all()
+    img = torch.rand(3, 2, 8, 8)
+    res = torch.zeros(3, 2, 8, 8, device=dev)
+    hip.rescale_elev(img.to(dev), res, 3, 2, 8)
+    ref_img = img.clone()
+    ref_img[:, 1:] = 30 * (ref_img[:, :1] - ref_img[:, 1:])
+    assert torch.equal(res.cpu(), ref_img)
 
 
 def test_depatchify(dev):
@@ -237,8 +255,8 @@ def test_gather_scatter_unmask(dev):
     mask = (inv < 0).to(torch.uint8).to(dev)
     dtok = torch.zeros(2, Dd, device=dev)
     dx = _rand(B, L, Dd, seed=6).to(dev)
-    hip.unmask_token_grad(dx, mask, slot, dtok, B, L, Dd, 0, 0, 24)
-    hip.unmask_token_grad(dx, mask, slot, dtok, B, L, Dd, 1, 24, L)
+    hip.unmask_token_grad(dx, mask, slot, dtok[0], B, L, Dd, 0, 0, 24)
+    hip.unmask_token_grad(dx, mask, slot, dtok[1], B, L, Dd, 1, 24, L)
     m = mask.bool()
     want0 = (dx * (m & (slot == 0)[None])[:, :, None]).sum((0, 1))
     want1 = (dx * (m & (slot == 1)[None])[:, :, None]).sum((0, 1))
