@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""MAE-pretrain tiles/sec on synthetic FLAIR-HUB-shaped batches (BASELINE.json metric), 1..8 MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = host mask draws + forward + masked loss + backward + (N>1: RCCL gradient all-reduce) + fused AdamW on
+a resident synthetic batch of B=32 tiles per GPU (weak scaling).  Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import maestro_amd.conf as conf  # noqa: E402
+
+# train GFLOP per tile (GEMM + attention matmuls, 3x forward) per workload
+WORKLOADS = {
+    "c2": dict(desc="ViT-B MAE, FLAIR aerial RGB+NIR 512x512x4 monotemporal", size="medium", gflop_tile=243.0,
+               ds=lambda: conf.DatasetsConfig(name_dataset="flair", flair=conf.FLAIRConfig(filter_inputs=["aerial"], filter_targets=[]))),
+    "c3": dict(desc="ViT-B MAE, FLAIR-HUB-shaped aerial 512x512x4 + Sentinel-2 16x10x10x10 time series", size="medium",
+               gflop_tile=330.0,
+               ds=lambda: conf.DatasetsConfig(name_dataset="flair", flair=conf.FLAIRConfig(filter_inputs=["aerial", "s2"], filter_targets=[]))),
+    "c3p": dict(desc="ViT-B MAE, full FLAIR-HUB (aerial, dem, s2, s1_asc, s1_des)", size="medium", gflop_tile=431.9,
+                ds=lambda: conf.DatasetsConfig(name_dataset="flair", flair=conf.FLAIRConfig(filter_targets=[]))),
+    "c4": dict(desc="ViT-L MAE, TreeSatAI-TS (aerial, s2, s1_asc, s1_des)", size="large", gflop_tile=262.1,
+               ds=lambda: conf.DatasetsConfig(name_dataset="treesatai_ts", treesatai_ts=conf.TreeSatAITSConfig(filter_targets=[]))),
+    "c5": dict(desc="ViT-B MAE, S2-NAIP-urban (aerial, spot, s2, s1), bf16 path", size="medium", gflop_tile=301.3,
+               ds=lambda: conf.DatasetsConfig(name_dataset="s2_naip", s2_naip=conf.S2NAIPConfig())),
+}
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_model(workload: str):
+    from maestro_amd.ssl import mae as pmae
+
+    w = WORKLOADS[workload]
+    ds = w["ds"]()
+    model = getattr(pmae, f"mae_{w['size']}")(datasets=ds, mask=conf.MaskConfig(), interpolate="nearest",
+                                              fusion_mode="group", inter_depth=3, model="mae", num_levels=1)
+    return ds, model
+
+
+def cpu_baseline(workload: str, seconds: float) -> dict:
+    """The oracle (CPU restatement = kind "port") timed on this node's host cores on a bounded sample."""
+    from maestro_amd.train.trainer import synthetic_batch
+    from oracle import mae as om
+
+    w = WORKLOADS[workload]
+    ds = w["ds"]()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.set_float32_matmul_precision("highest")
+    torch.manual_seed(42)
+    model = om.build_oracle(ds, conf.MaskConfig(), model_size=w["size"], interpolate="nearest", fusion_mode="group",
+                            inter_depth=3, model="mae", num_levels=1)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.99), weight_decay=0.01)
+    B = 2  # noqa: N806
+    batch = synthetic_batch(ds.dataset, B, "cpu")
+    times = []
+    t_end = time.time() + seconds
+    for i in range(50):
+        t0 = time.time()
+        loss, _, _ = om.oracle_step(model, batch, "l2_norm")
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        dt = time.time() - t0
+        if i > 0:
+            times.append(dt)
+        if time.time() > t_end and len(times) >= 1:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} timed steps (after 1 warm-up) of the same {workload} workload at B={B}, fp32, "
+                      f"torch CPU threads={cores}, forward+loss+backward+AdamW"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=32, help="tiles per GPU (reference default, conf/opt.py:20)")
+    ap.add_argument("--loss", default="l2_norm")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from maestro_amd import hip
+    from maestro_amd.train.trainer import PretrainLoop, synthetic_batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    torch.manual_seed(42 + rank)
+    ds, model = build_model(args.config)
+    loop = PretrainLoop(model, args.batch, dev, loss=args.loss, total_steps=args.steps + args.warmup, world_size=world)
+    batch = synthetic_batch(ds.dataset, args.batch, dev, seed=rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loop.step(batch)
+    timer = None if args.no_kernel_timing else hip.KernelTimer()
+    sync()
+    t0 = time.perf_counter()
+    if timer is not None:
+        hip.set_kernel_timer(timer)
+    for _ in range(args.steps):
+        loss = loop.step(batch)
+    hip.set_kernel_timer(None)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        tiles = args.batch * world * args.steps
+        value = tiles / elapsed
+        w = WORKLOADS[args.config]
+        out = {
+            "metric": "MAE-pretrain tiles/sec", "value": round(value, 2), "unit": "tiles/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {w['desc']}", "tiles_per_gpu": args.batch,
+                       "global_batch": args.batch * world, "loss": args.loss, "fusion_mode": "group", "inter_depth": 3,
+                       "parallelism": f"dp{world}", "params_M": round(loop.engine.store.total / 1e6, 1),
+                       "final_loss": round(loss_val, 5)},
+            "whole_step": {"train_gflop_per_tile": w["gflop_tile"],
+                           "mfma_frac": round(value / world * w["gflop_tile"] / 1e3 / MFMA_PEAK_TFLOPS, 4)},
+        }
+        if timer is not None:
+            out["roofline"] = timer.roofline(MFMA_PEAK_TFLOPS)
+            out["kernel_times_ms_per_step"] = timer.summary(args.steps)
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,11 +54,15 @@ int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const 
 int mh_layernorm_fwd(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y, int y_L,
                      int y_off, int y_is_f32, float* mean, float* rstd, int B, int n, int dim, float eps, void* stream);
 /* dx (f32, x's row map) = (dres ? dres : 0) + LN-backward(dy); optional bf16 copy dx_bf16 (operand of the next
- * dgrad/wgrad GEMM).  dgamma/dbeta f32 [dim] are ATOMICALLY accumulated (caller zeroes grads once per step); pass
- * both NULL to skip.  dy is bf16 (dy_is_f32 = 0) or f32, addressed with its own row map. */
+ * dgrad/wgrad GEMM).  dgamma/dbeta f32 [dim] are accumulated (+=) through `workspace` (f32,
+ * mh_layernorm_bwd_workspace(B*n, dim) floats; per-block partial rows, then a short atomic reduce); dcol f32 [dim]
+ * (optional) += column sums of dx = the bias gradient of the Linear whose output fed this residual.  Pass
+ * dgamma = dbeta = NULL to skip all three.  dy is bf16 (dy_is_f32 = 0) or f32, addressed with its own row map. */
 int mh_layernorm_bwd(const void* dy, int dy_L, int dy_off, int dy_is_f32, const float* x, int x_L, int x_off,
                      const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
-                     void* dx_bf16, float* dgamma, float* dbeta, int B, int n, int dim, void* stream);
+                     void* dx_bf16, float* dgamma, float* dbeta, float* dcol, float* workspace, int B, int n, int dim,
+                     void* stream);
+long mh_layernorm_bwd_workspace(int rows, int dim);
 
 /* ---------------------------------------------------------------------------------------------- attention
  * Fused softmax(Q K^T * scale) V, no mask, no dropout (vit_pytorch Attention.forward; call sites mae.py:135-174).

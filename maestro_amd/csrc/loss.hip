@@ -136,7 +136,10 @@ extern "C" int mh_masked_loss(const float* rec, const float* target, const uint8
 
 extern "C" int mh_colsum(const void* x, int x_is_f32, float* out, int M, int N, int ld, void* stream) {
     MH_CHECK_ARG(x && out && N % 4 == 0 && ld % 4 == 0, "mh_colsum: bad arguments");
-    const int rows_per_block = 512;
+    // enough blocks to fill 256 CUs (>= ~1024) while keeping a few hundred atomics per column at most
+    const int col_blocks = ceil_div(N, 256);
+    int rows_per_block = 512;
+    while (rows_per_block > 32 && (long)col_blocks * ceil_div(M, rows_per_block) < 1024) rows_per_block >>= 1;
     hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 256), ceil_div(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream, x,
                        x_is_f32, out, M, N, ld, rows_per_block);
     MH_LAUNCH_CHECK();

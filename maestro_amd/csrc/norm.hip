@@ -8,11 +8,11 @@
 
 namespace {
 
-constexpr int MAXV = 8;  // float4 per lane -> dim <= 2048
-
 struct RowMap { int L, off; };
 __device__ __forceinline__ size_t map_row(RowMap m, int b, int j) { return (size_t)b * m.L + m.off + j; }
 
+// NV = float4 per lane (dim <= 256*NV); registers are sized exactly for the row width (no spills).
+template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, RowMap xm, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, void* __restrict__ y, RowMap ym,
                                                      int y_is_f32, float* __restrict__ mean, float* __restrict__ rstd,
@@ -23,22 +23,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const int b = row / n, j = row - b * n;
     const float* xr = x + map_row(xm, b, j) * dim;
     const int nv = dim >> 2;
-    f32x4 v[MAXV];
+    f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
-        if (c < nv) {
-            v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
+        v[i] = (f32x4){0, 0, 0, 0};
+        if (c < nv) v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mu = wave_sum(s) / dim;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
+    for (int i = 0; i < NV; ++i) {
+        if (lane + 64 * i < nv) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; }
         }
@@ -47,7 +45,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     const size_t yrow = map_row(ym, b, j) * dim;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
@@ -65,24 +63,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-// Backward. Each wave walks ROWS_PER_WAVE rows, keeps dgamma/dbeta partials in registers, the block reduces them
-// through LDS and issues one atomic per column.
+// Backward. Each wave walks ROWS_PER_WAVE rows keeping per-column partials of dgamma, dbeta and colsum(dx) in
+// registers; the block reduces them through LDS and writes ONE partial row [3*dim] to the workspace (plain stores);
+// ln_bwd_reduce_kernel then sums the partial rows (few atomics per column, no same-address storm).
 constexpr int ROWS_PER_WAVE = 8;
 
+template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, RowMap dym, int dy_is_f32,
                                                      const float* __restrict__ x, RowMap xm,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      float* __restrict__ dx, bf16_t* __restrict__ dx_bf16,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int n,
-                                                     int dim) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][dim]
+                                                     float* __restrict__ partial, int B, int n, int dim) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][3][dim]
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nv = dim >> 2;
-    f32x4 gsum[MAXV], bsum[MAXV], gm[MAXV];
+    f32x4 gsum[NV], bsum[NV], csum[NV], gm[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        gsum[i] = (f32x4){0, 0, 0, 0}; bsum[i] = (f32x4){0, 0, 0, 0};
+    for (int i = 0; i < NV; ++i) {
+        gsum[i] = (f32x4){0, 0, 0, 0}; bsum[i] = (f32x4){0, 0, 0, 0}; csum[i] = (f32x4){0, 0, 0, 0};
         const int c = lane + 64 * i;
         gm[i] = c < nv ? *reinterpret_cast<const f32x4*>(gamma + 4 * c) : (f32x4){0, 0, 0, 0};
     }
@@ -93,11 +92,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         const int b = row / n, j = row - b * n;
         const size_t xrow = map_row(xm, b, j) * dim, dyrow = map_row(dym, b, j) * dim;
         const float mu = mean[row], rs = rstd[row];
-        f32x4 xh[MAXV], dz[MAXV];
+        f32x4 xh[NV], dz[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
+            xh[i] = (f32x4){0, 0, 0, 0}; dz[i] = (f32x4){0, 0, 0, 0};
             if (c < nv) {
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(x + xrow + 4 * c);
                 f32x4 d;
@@ -121,13 +121,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         }
         const float c1 = wave_sum(s1) / dim, c2 = wave_sum(s2) / dim;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (dz[i][e] - c1 - xh[i][e] * c2);
                 if (dres) o += *reinterpret_cast<const f32x4*>(dres + xrow + 4 * c);
+                csum[i] += o;
                 *reinterpret_cast<f32x4*>(dx + xrow + 4 * c) = o;
                 if (dx_bf16) {
                     u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
@@ -136,50 +137,86 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             }
         }
     }
-    if (!dgamma) return;
-    float* rg = red + (size_t)w * 2 * dim;
+    if (!partial) return;
+    float* rg = red + (size_t)w * 3 * dim;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
             *reinterpret_cast<f32x4*>(rg + 4 * c) = gsum[i];
             *reinterpret_cast<f32x4*>(rg + dim + 4 * c) = bsum[i];
+            *reinterpret_cast<f32x4*>(rg + 2 * dim + 4 * c) = csum[i];
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * dim; c += 256) {
-        const float t = red[c] + red[2 * dim + c] + red[4 * dim + c] + red[6 * dim + c];
-        if (c < dim) atomicAdd(dgamma + c, t); else atomicAdd(dbeta + (c - dim), t);
-    }
+    float* prow = partial + (size_t)blockIdx.x * 3 * dim;
+    for (int c = threadIdx.x; c < 3 * dim; c += 256)
+        prow[c] = red[c] + red[3 * dim + c] + red[6 * dim + c] + red[9 * dim + c];
+}
+
+constexpr int RED_ROWS = 32;
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int dim,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ dcol) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 3 * dim) return;
+    const int r0 = blockIdx.y * RED_ROWS, r1 = min(nblk, r0 + RED_ROWS);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += partial[(size_t)r * 3 * dim + c];
+    if (c < dim) atomicAdd(dgamma + c, s);
+    else if (c < 2 * dim) atomicAdd(dbeta + (c - dim), s);
+    else if (dcol) atomicAdd(dcol + (c - 2 * dim), s);
 }
 
 }  // namespace
+
+static int ln_nv(int dim) { const int v = (dim / 4 + 63) / 64; return v <= 4 ? v : 8; }
 
 extern "C" int mh_layernorm_fwd(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y,
                                 int y_L, int y_off, int y_is_f32, float* mean, float* rstd, int B, int n, int dim,
                                 float eps, void* stream) {
     MH_CHECK_ARG(x && gamma && beta && y && mean && rstd, "mh_layernorm_fwd: null pointer");
-    MH_CHECK_ARG(dim % 4 == 0 && dim >= 4 && dim <= 4 * 64 * MAXV, "mh_layernorm_fwd: dim %d unsupported", dim);
+    MH_CHECK_ARG(dim % 4 == 0 && dim >= 4 && dim <= 2048, "mh_layernorm_fwd: dim %d unsupported", dim);
     MH_CHECK_ARG(B > 0 && n > 0 && x_off + n <= x_L && y_off + n <= y_L, "mh_layernorm_fwd: bad row map");
     const int rows = B * n;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, RowMap{x_L, x_off},
-                       gamma, beta, y, RowMap{y_L, y_off}, y_is_f32, mean, rstd, B, n, dim, eps);
+    dim3 grid(ceil_div(rows, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LN_FWD(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, grid, block, 0, s, x, RowMap{x_L, x_off}, gamma, beta, y, \
+                                      RowMap{y_L, y_off}, y_is_f32, mean, rstd, B, n, dim, eps)
+    switch (ln_nv(dim)) { case 1: LN_FWD(1); break; case 2: LN_FWD(2); break; case 3: LN_FWD(3); break;
+                          case 4: LN_FWD(4); break; default: LN_FWD(8); }
+#undef LN_FWD
     MH_LAUNCH_CHECK();
     return 0;
 }
 
+extern "C" long mh_layernorm_bwd_workspace(int rows, int dim) {
+    return (long)ceil_div(rows, 4 * ROWS_PER_WAVE) * 3 * dim;
+}
+
 extern "C" int mh_layernorm_bwd(const void* dy, int dy_L, int dy_off, int dy_is_f32, const float* x, int x_L, int x_off,
                                 const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
-                                void* dx_bf16, float* dgamma, float* dbeta, int B, int n, int dim, void* stream) {
+                                void* dx_bf16, float* dgamma, float* dbeta, float* dcol, float* workspace, int B, int n,
+                                int dim, void* stream) {
     MH_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "mh_layernorm_bwd: null pointer");
     MH_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "mh_layernorm_bwd: dgamma/dbeta must come together");
-    MH_CHECK_ARG(dim % 4 == 0 && dim >= 4 && dim <= 4 * 64 * MAXV, "mh_layernorm_bwd: dim %d unsupported", dim);
+    MH_CHECK_ARG(!dgamma || workspace, "mh_layernorm_bwd: parameter gradients need the workspace");
+    MH_CHECK_ARG(!dcol || dgamma, "mh_layernorm_bwd: dcol needs dgamma/dbeta");
+    MH_CHECK_ARG(dim % 4 == 0 && dim >= 4 && dim <= 2048, "mh_layernorm_bwd: dim %d unsupported", dim);
     MH_CHECK_ARG(B > 0 && n > 0 && x_off + n <= x_L && dy_off + n <= dy_L, "mh_layernorm_bwd: bad row map");
-    const int rows = B * n;
-    const size_t lds = (size_t)4 * 2 * dim * sizeof(float);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(rows, 4 * ROWS_PER_WAVE)), dim3(256), lds, (hipStream_t)stream, dy,
-                       RowMap{dy_L, dy_off}, dy_is_f32, x, RowMap{x_L, x_off}, gamma, mean, rstd, dres, dx,
-                       (bf16_t*)dx_bf16, dgamma, dbeta, B, n, dim);
+    const int rows = B * n, nblk = ceil_div(rows, 4 * ROWS_PER_WAVE);
+    const size_t lds = (size_t)4 * 3 * dim * sizeof(float);
+    dim3 grid(nblk), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    float* part = dgamma ? workspace : nullptr;
+#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, lds, s, dy, RowMap{dy_L, dy_off}, dy_is_f32, x, \
+                                      RowMap{x_L, x_off}, gamma, mean, rstd, dres, dx, (bf16_t*)dx_bf16, part, B, n, dim)
+    switch (ln_nv(dim)) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break;
+                          case 4: LN_BWD(4); break; default: LN_BWD(8); }
+#undef LN_BWD
+    if (dgamma)
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(3 * dim, 256), ceil_div(nblk, RED_ROWS)), dim3(256), 0, s,
+                           workspace, nblk, dim, dgamma, dbeta, dcol);
     MH_LAUNCH_CHECK();
     return 0;
 }

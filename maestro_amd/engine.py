@@ -113,6 +113,10 @@ class Stack:
     def x_last(self):
         return self.xs[-1]
 
+    def top_bias_grad(self):
+        """Gradient slot of the last layer's fc2 bias: it equals colsum(d x_last), produced by the final-LN backward."""
+        return self.eng.store.g(self.t.layers[-1][1].net[4].bias) if self.depth else None
+
     def forward(self) -> None:
         eng, ps, M = self.eng, self.eng.store, self.M  # noqa: N806
         dim, mlp, inner = self.dim, self.mlp, self.inner
@@ -146,24 +150,23 @@ class Stack:
             hip.gemm(hip.GEMM_NN, M, mlp, dim, cur16, dim, ps.h(fc2.weight), mlp, self.dh, mlp, hip.DGELU,
                      aux_in=s["hpre"], ldaux=mlp)
             hip.gemm(hip.GEMM_TN, dim, mlp, M, cur16, dim, s["act"], mlp, ps.g(fc2.weight), mlp, AT)
-            hip.colsum(cur16, ps.g(fc2.bias), M, dim, dim)
             hip.gemm(hip.GEMM_NN, M, dim, mlp, self.dh, mlp, ps.h(fc1.weight), dim, self.dh2, dim)
             hip.gemm(hip.GEMM_TN, mlp, dim, M, self.dh, mlp, s["h2"], dim, ps.g(fc1.weight), dim, AT)
             hip.colsum(self.dh, ps.g(fc1.bias), M, mlp, mlp)
-            hip.layernorm_bwd(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16,
-                              ps.g(ln2.weight), ps.g(ln2.bias), 1, M, dim)
-            # ---- attention: x_mid = x_in + proj(attn(qkv(LN1(x_in))))
             proj = attn.to_out[0]
+            hip.layernorm_bwd(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16,
+                              ps.g(ln2.weight), ps.g(ln2.bias), ps.g(proj.bias), eng.ln_ws, 1, M, dim)
+            # ---- attention: x_mid = x_in + proj(attn(qkv(LN1(x_in))))
             nxt, nxt16 = (self.dxa, self.dxa16) if mid is not self.dxa else (self.dxb, self.dxb16)
             hip.gemm(hip.GEMM_NN, M, inner, dim, mid16, dim, ps.h(proj.weight), inner, self.do, inner)
             hip.gemm(hip.GEMM_TN, dim, inner, M, mid16, dim, s["o"], inner, ps.g(proj.weight), inner, AT)
-            hip.colsum(mid16, ps.g(proj.bias), M, dim, dim)
             hip.attn_bwd(s["qkv"], s["o"], self.do, s["lse"], self.delta, self.dqkv, self.Bn, self.N, self.H, self.Dh,
                          attn.scale)
             hip.gemm(hip.GEMM_NN, M, dim, 3 * inner, self.dqkv, 3 * inner, ps.h(attn.to_qkv.weight), dim, self.dh2, dim)
             hip.gemm(hip.GEMM_TN, 3 * inner, dim, M, self.dqkv, 3 * inner, s["h1"], dim, ps.g(attn.to_qkv.weight), dim, AT)
+            prev_fc2_bias = ps.g(self.t.layers[l - 1][1].net[4].bias) if l > 0 else None  # = colsum(dx_out of layer l-1)
             hip.layernorm_bwd(self.dh2, M, 0, x_in, M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid, nxt, nxt16,
-                              ps.g(attn.norm.weight), ps.g(attn.norm.bias), 1, M, dim)
+                              ps.g(attn.norm.weight), ps.g(attn.norm.bias), prev_fc2_bias, eng.ln_ws, 1, M, dim)
             cur, cur16 = nxt, nxt16
             eng._grads_ready(self.t.layers[l])
         return cur
@@ -257,6 +260,8 @@ class MAEEngine:
             self.joint = Stack(self, m.encoder_inter, self.B, m.joint_N, "joint")
         else:
             self.joint = None
+        stacks = list(self.enc.values()) + list(self.dec.values()) + ([self.joint] if self.joint is not None else [])
+        self.ln_ws = e(max(hip.layernorm_bwd_workspace(st.M, st.dim) for st in stacks))
         self.loss_acc = z(1)
         tot_w = sum(s.Dates * s.L for s in self.mods.values())
         self.loss_w = {n: (s.Dates * s.L) / tot_w for n, s in self.mods.items()}  # weight = D*H*W (model.py:239)
@@ -394,7 +399,8 @@ class MAEEngine:
                 hip.gemm(hip.GEMM_TN, s.K, Dd, T, b["drec"], s.K, b["hdec"], Dd, ps.g(conv.weight).view(s.K, Dd), Dd, AT)
                 hip.colsum(b["drec"], ps.g(conv.bias), T, s.K, s.K)
                 hip.layernorm_bwd(b["dh"], s.n_tok, 0, st.x_last, g.L, s.tok_off, nrm.weight, b["mean_f"], b["rstd_f"], None,
-                                  dx, dx16, ps.g(nrm.weight), ps.g(nrm.bias), s.Beff, s.n_tok, Dd)
+                                  dx, dx16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(), self.ln_ws, s.Beff,
+                                  s.n_tok, Dd)
                 self._grads_ready(m.embed_to_rec[s.embed])
             dx0 = st.backward(dx, dx16)
             self._grads_ready(nrm)
@@ -417,7 +423,8 @@ class MAEEngine:
             for g in self.groups:
                 gbuf = self.gb[g.name]
                 hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, jt.x_last, m.joint_N, g.joint_off, nrm.weight, gbuf["mean_j"],
-                                  gbuf["rstd_j"], None, jt.dxa, jt.dxa16, ps.g(nrm.weight), ps.g(nrm.bias), g.Beff, g.N, E)
+                                  gbuf["rstd_j"], None, jt.dxa, jt.dxa16, ps.g(nrm.weight), ps.g(nrm.bias),
+                                  jt.top_bias_grad(), self.ln_ws, g.Beff, g.N, E)
             djoint = jt.backward(jt.dxa, jt.dxa16)
             self._grads_ready(nrm)
         for g in reversed(self.groups):
@@ -425,10 +432,12 @@ class MAEEngine:
             nrm = st.t.norm
             if self.joint is not None:
                 hip.layernorm_bwd(djoint, m.joint_N, g.joint_off, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"],
-                                  gbuf["rstd_e"], None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias), g.Beff, g.N, E)
+                                  gbuf["rstd_e"], None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias),
+                                  st.top_bias_grad(), self.ln_ws, g.Beff, g.N, E)
             else:
                 hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"], gbuf["rstd_e"],
-                                  None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias), g.Beff, g.N, E)
+                                  None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(), self.ln_ws,
+                                  g.Beff, g.N, E)
             dx0 = st.backward(st.dxa, st.dxa16)
             self._grads_ready(nrm)
             # scatter to the full group sequence (masked tokens get zero), then patch-embed backward per modality

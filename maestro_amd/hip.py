@@ -80,9 +80,16 @@ def layernorm_fwd(x, x_L, x_off, gamma, beta, y, y_L, y_off, mean, rstd, B, n, d
          _I(1 if y.dtype == torch.float32 else 0), mean, rstd, _I(B), _I(n), _I(dim), _F(eps))
 
 
-def layernorm_bwd(dy, dy_L, dy_off, x, x_L, x_off, gamma, mean, rstd, dres, dx, dx_bf16, dgamma, dbeta, B, n, dim):
+def layernorm_bwd_workspace(rows, dim) -> int:
+    f = lib().mh_layernorm_bwd_workspace
+    f.restype = ctypes.c_long
+    return int(f(_I(rows), _I(dim)))
+
+
+def layernorm_bwd(dy, dy_L, dy_off, x, x_L, x_off, gamma, mean, rstd, dres, dx, dx_bf16, dgamma, dbeta, dcol, workspace,
+                  B, n, dim):
     call("mh_layernorm_bwd", dy, _I(dy_L), _I(dy_off), _I(1 if dy.dtype == torch.float32 else 0), x, _I(x_L), _I(x_off),
-         gamma, mean, rstd, dres, dx, dx_bf16, dgamma, dbeta, _I(B), _I(n), _I(dim))
+         gamma, mean, rstd, dres, dx, dx_bf16, dgamma, dbeta, dcol, workspace, _I(B), _I(n), _I(dim))
 
 
 def attn_fwd(qkv, out, lse, B, N, H, D, scale):
@@ -176,3 +183,76 @@ def unpack_rows_add(src, dst, E, K, Kpad):
 
 def adamw(p, g, m, v, p_bf16, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
     call("mh_adamw", p, g, m, v, p_bf16, _L(n), _F(lr), _F(b1), _F(b2), _F(eps), _F(wd), _I(step), _F(grad_scale))
+
+
+# ------------------------------------------------------------------------------------------------ kernel timing
+class KernelTimer:
+    """HIP-event timing of the MFMA kernels on the stream they are launched on (bench.py's roofline leg)."""
+
+    def __init__(self) -> None:
+        self.events: dict[str, list] = {}
+        self.flops: dict[str, float] = {}
+        self.count: dict[str, int] = {}
+
+    def record(self, kind: str, flops: float):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.events.setdefault(kind, []).append((e0, e1))
+        self.flops[kind] = self.flops.get(kind, 0.0) + flops
+        self.count[kind] = self.count.get(kind, 0) + 1
+        return e0, e1
+
+    def totals(self) -> dict[str, float]:
+        torch.cuda.synchronize()
+        return {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.events.items()}  # ms
+
+    def summary(self, steps: int) -> dict:
+        return {k: round(v / steps, 3) for k, v in self.totals().items()}
+
+    def roofline(self, peak_tflops: float) -> dict:
+        tot = self.totals()
+        kind = max(tot, key=tot.get)
+        achieved = self.flops[kind] / (tot[kind] * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": kind, "achieved": round(achieved, 1), "peak": peak_tflops, "unit": "TFLOP/s",
+                "frac": round(achieved / peak_tflops, 4), "launches": self.count[kind],
+                "avg_launch_us": round(1e3 * tot[kind] / self.count[kind], 2),
+                "flops_per_launch": round(self.flops[kind] / self.count[kind]), "traffic": None}
+
+
+_timer: KernelTimer | None = None
+_GEMM_KERNEL = {GEMM_NT: "gemm_kernel<NT>", GEMM_NN: "gemm_kernel<NN>", GEMM_TN: "gemm_kernel<TN>"}
+
+
+def set_kernel_timer(t: KernelTimer | None) -> None:
+    global _timer
+    _timer = t
+
+
+_gemm_raw = gemm
+_attn_fwd_raw, _attn_bwd_raw = attn_fwd, attn_bwd
+
+
+def gemm(layout, M, N, K, *a, **k):  # noqa: F811
+    if _timer is None:
+        return _gemm_raw(layout, M, N, K, *a, **k)
+    e0, e1 = _timer.record(_GEMM_KERNEL[layout], 2.0 * M * N * K)
+    e0.record()
+    _gemm_raw(layout, M, N, K, *a, **k)
+    e1.record()
+
+
+def attn_fwd(qkv, out, lse, B, N, H, D, scale):  # noqa: F811
+    if _timer is None:
+        return _attn_fwd_raw(qkv, out, lse, B, N, H, D, scale)
+    e0, e1 = _timer.record("attn_fwd", 4.0 * B * H * N * N * D)
+    e0.record()
+    _attn_fwd_raw(qkv, out, lse, B, N, H, D, scale)
+    e1.record()
+
+
+def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):  # noqa: F811
+    if _timer is None:
+        return _attn_bwd_raw(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale)
+    e0, e1 = _timer.record("attn_bwd", 10.0 * B * H * N * N * D)  # algorithmic 5 matmuls (the kernels recompute 2 more)
+    e0.record()
+    _attn_bwd_raw(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale)
+    e1.record()

@@ -1,0 +1,192 @@
+"""``SSLModule``: the Lightning-module surface of the reference (``maestro/train/model.py`` + ``train/base.py``)
+on top of the HIP engine.
+
+Same constructor, ``training_step/validation_step/test_step`` outputs (``loss, log_inputs, log_preds, log_targets``),
+``configure_optimizers`` rule, ``metrics["loss_rec_<stage>"]``, ``model`` / ``ema_model`` / ``dataset`` attributes and
+state-dict keys.  ``pytorch_lightning`` is optional: when it is importable the class derives from
+``LightningModule`` (so ``Trainer.fit`` drives it unchanged); otherwise from ``nn.Module`` and the built-in
+``maestro_amd.train.trainer.fit`` loop drives it.  ``loss`` is a real autograd leaf-connected tensor: calling
+``loss.backward()`` (what Lightning does) runs the engine's hand-written backward.
+"""
+
+from __future__ import annotations
+
+import copy
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from maestro_amd.ssl.mae import mae_large, mae_medium, mae_small, mae_tiny
+
+try:  # optional dependency, exactly as in the reference's environment
+    from pytorch_lightning import LightningModule as _Base
+except Exception:  # noqa: BLE001
+    class _Base(nn.Module):
+        def save_hyperparameters(self, *a, **k):
+            return None
+
+        def log(self, *a, **k):
+            return None
+
+
+class MeanMetric(nn.Module):
+    """Minimal stand-in for ``torchmetrics.MeanMetric`` (running mean of a scalar; ``base.py:52-56``)."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.total, self.count = 0.0, 0
+
+    def update(self, value) -> None:
+        self._pending = value.detach() if isinstance(value, torch.Tensor) else value
+        self.total, self.count = self.total + float(self._pending), self.count + 1
+
+    def compute(self) -> float:
+        return self.total / max(self.count, 1)
+
+    def reset(self) -> None:
+        self.total, self.count = 0.0, 0
+
+
+class _EngineLoss(torch.autograd.Function):
+    """Bridges autograd and the engine: forward = engine loss (already computed), backward = engine.backward()."""
+
+    @staticmethod
+    def forward(ctx, anchor, engine, loss_value):  # noqa: ARG004
+        ctx.engine = engine
+        return loss_value.clone().reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        eng = ctx.engine
+        eng.zero_grad()
+        eng.backward()
+        st = eng.store
+        if not (isinstance(grad_out, torch.Tensor) and grad_out.numel() == 1 and float(grad_out) == 1.0):
+            st.grad.mul_(grad_out.reshape(()))  # e.g. gradient accumulation / loss scaling by the trainer
+        for p in st.params:  # re-attach views if the trainer cleared them (zero_grad(set_to_none=True))
+            if p.grad is None or p.grad.data_ptr() != st.g(p).data_ptr():
+                p.grad = st.g(p)
+        return None, None, None
+
+
+class SSLModule(_Base):
+    """SSL module (pretrain branch on the MI355X engine)."""
+
+    def __init__(self, datasets, mask, interpolate, fusion_mode, inter_depth, model, model_size, type_head="attentive",
+                 loss="l2_norm", use_date_enc=True, use_ema=False) -> None:
+        super().__init__()
+        self.dataset = datasets.dataset
+        self.metrics = nn.ModuleDict({f"{n}_{s}": MeanMetric() for n in ("loss_rec", "loss_pred")
+                                      for s in ("train", "val", "test")})
+        self.norm_bands = {
+            m: tuple(c.norm_bands if c.norm_bands is not None
+                     else ([c.bands] if isinstance(c.bands, int) else [len(b) for b in c.bands]))
+            for m, c in datasets.dataset.inputs.items()}
+        if loss not in ("l1", "l2", "l1_norm", "l2_norm"):
+            raise ValueError(f"Invalid loss {loss}.")
+        self.loss_name, self.norm_pix_loss = loss, loss.endswith("_norm")
+        if model != "mae":
+            raise ValueError(f"Invalid model name {model}. Not implemented")
+        model_map = {"tiny": mae_tiny, "small": mae_small, "medium": mae_medium, "large": mae_large}
+        if inter_depth and fusion_mode not in ("mod", "group"):
+            raise NotImplementedError(
+                f"Simultaneous encoding of all mods not yet compatible with fusion mode: {fusion_mode}.")
+        if model_size not in model_map:
+            raise ValueError(f"Invalid model size {model_size}. Expected one of {model_map.keys()}")
+        self.model = model_map[model_size](
+            datasets=datasets, mask=mask, interpolate=interpolate, fusion_mode=fusion_mode, inter_depth=inter_depth,
+            model=model, num_levels=1, type_head=type_head, fac_abs_enc=1.0, fac_date_enc=1.0 if use_date_enc else 0.0)
+        if use_ema:
+            self.ema_model = copy.deepcopy(self.model).to("cpu")
+            for p in self.ema_model.parameters():
+                p.requires_grad = False
+        else:
+            self.ema_model = None
+        self._anchor = nn.Parameter(torch.zeros(()), requires_grad=True)  # autograd entry point of the engine
+        self.save_hyperparameters(ignore=["datasets"])
+        if not hasattr(self, "trainer") or getattr(self, "_trainer", None) is None:
+            try:
+                self.trainer = SimpleNamespace(ssl_phase="pretrain")
+            except Exception:  # noqa: BLE001  (Lightning exposes trainer as a property that raises when detached)
+                pass
+
+    # ------------------------------------------------------------------ optimisers (reference rule)
+    def configure_optimizers(self) -> dict:
+        tr = self.trainer
+        total_batch = tr.train_dataloader.batch_size * tr.accumulate_grad_batches * tr.num_nodes * tr.num_devices / 3.0
+        lr = tr.base_lr * total_batch**0.5
+        params = [p for n, p in self.named_parameters() if n != "_anchor"]
+        optimizer = torch.optim.AdamW(params, lr=lr, weight_decay=tr.wd, betas=(tr.b1, tr.b2))
+        scheduler = torch.optim.lr_scheduler.OneCycleLR(
+            optimizer, max_lr=lr, total_steps=tr.estimated_stepping_batches, pct_start=0.2, cycle_momentum=False,
+            div_factor=1000, final_div_factor=tr.final_factor / 1000.0)
+        return {"optimizer": optimizer,
+                "lr_scheduler": {"scheduler": scheduler, "interval": "step", "name": f"{tr.ssl_phase}_AdamW_lr"}}
+
+    # ------------------------------------------------------------------ steps
+    def _ssl_phase(self) -> str:
+        return getattr(getattr(self, "trainer", None), "ssl_phase", "pretrain")
+
+    def compute_loss_rec(self, engine, stage: str) -> torch.Tensor:
+        """Masked reconstruction loss of the last forward (computed on the GPU by ``mh_masked_loss``)."""
+        loss = _EngineLoss.apply(self._anchor, engine, engine.loss_acc)
+        self.metrics[f"loss_rec_{stage}"].update(loss)
+        return loss
+
+    def compute_logs_rec(self, batch, engine, ssl_phase: str, stage: str):
+        """Visualisation tensors for sample [0, 0] only, built lazily (the reference recomputes them every step)."""
+        log_inputs, log_preds, log_targets = {}, {}, {}
+
+        def lazy(kind, name_mod):
+            def make():
+                pixels, masks = engine.reconstructions()
+                msk, tgt, rec = masks[name_mod][0, 0], batch[name_mod][0, 0], pixels[name_mod][0, 0]
+                if kind == "input":
+                    out = torch.where(msk, torch.zeros_like(tgt), tgt)
+                    return torch.where(msk.all(dim=0, keepdim=True), torch.ones_like(tgt), out)
+                return torch.where(msk, rec, tgt) if kind == "rec" else tgt
+            return make
+
+        for name_mod in self.model.mod_specs:
+            if name_mod not in self.dataset.log_inputs:
+                continue
+            log_inputs[f"{ssl_phase}_{stage}/_{name_mod}_input"] = lazy("input", name_mod)
+            log_preds[f"{ssl_phase}_{stage}/_{name_mod}_rec"] = lazy("rec", name_mod)
+            log_targets[f"{ssl_phase}_{stage}/_{name_mod}_target"] = lazy("target", name_mod)
+        return log_inputs, log_preds, log_targets
+
+    def pretrain_step(self, batch: dict, stage: str) -> dict:
+        first = next(iter(self.dataset.inputs))
+        engine = self.model.engine(batch[first].shape[0], batch[first].device, loss=self.loss_name)
+        engine.forward(batch)
+        loss = self.compute_loss_rec(engine, stage)
+        log_inputs, log_preds, log_targets = self.compute_logs_rec(batch, engine, self._ssl_phase(), stage)
+        return {"loss": loss, "log_inputs": log_inputs, "log_preds": log_preds, "log_targets": log_targets}
+
+    def shared_step(self, batch: dict, stage: str) -> dict:
+        phase = self._ssl_phase()
+        if phase == "pretrain":
+            return self.pretrain_step(batch, stage)
+        if phase in ("probe", "finetune"):
+            raise NotImplementedError("probe/finetune steps are a SURVEY §8(f) 'next' row")
+        raise ValueError(f"Invalid ssl phase {phase}. Expected 'pretrain' or 'probe' or 'finetune'")
+
+    def training_step(self, batch: dict, batch_idx: int) -> dict:  # noqa: ARG002
+        return self.shared_step(batch, stage="train")
+
+    def validation_step(self, batch: dict, batch_idx: int) -> dict:  # noqa: ARG002
+        return self.shared_step(batch, stage="val")
+
+    def test_step(self, batch: dict, batch_idx: int) -> dict:  # noqa: ARG002
+        return self.shared_step(batch, stage="test")
+
+    def on_train_epoch_end(self) -> None:
+        if self.ema_model is not None:
+            self.update_ema()
+
+    def update_ema(self) -> None:
+        """Per-epoch EMA of the weights (``base.py:263-274``); off the per-step path."""
+        momentum = 1 - 1 / (self.trainer.max_epochs * 0.2)
+        for p, pe in zip(self.model.parameters(), self.ema_model.parameters()):
+            pe.data.mul_(momentum).add_((1.0 - momentum) * p.detach().data.to(pe.device))

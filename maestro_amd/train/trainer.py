@@ -1,0 +1,70 @@
+"""Minimal built-in pretraining loop (one process per GPU) used by bench.py and when Lightning is absent.
+
+Step = host mask draws -> engine forward (+ loss) -> engine backward with bucketed RCCL all-reduce overlapped ->
+fused AdamW (+ OneCycle LR).  Mirrors what Lightning's loop does around ``SSLModule.training_step`` for the
+pretrain phase (reference ``maestro/train/trainer.py:116-126``, ``maestro/run_experiment.py:76-91``); checkpoints,
+loggers and callbacks are host orchestration and out of scope.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from maestro_amd.train.ddp import GradSync
+from maestro_amd.train.optim import FusedAdamW, OneCycle, scaled_lr
+
+
+def synthetic_batch(dataset, B: int, device, seed: int = 0) -> dict:  # noqa: N803
+    """Deterministic FLAIR-HUB-shaped synthetic batch: rasters U[0,1) fp32, int16 dates."""
+    batch = {}
+    for i, (name, c) in enumerate(dataset.inputs.items()):
+        g = torch.Generator().manual_seed(1234 + i + 1000 * seed)
+        C = c.bands if isinstance(c.bands, int) else sum(len(b) for b in c.bands)  # noqa: N806
+        batch[name] = torch.rand(B, c.num_dates, C, c.image_size, c.image_size, generator=g).to(device)
+        d = torch.arange(c.num_dates)
+        dates = torch.stack([torch.full_like(d, 2019), 100 + 7 * d, torch.full_like(d, 10)], dim=-1)
+        batch[f"{name}_dates"] = dates[None].expand(B, -1, -1).contiguous().to(torch.int16).to(device)
+    batch["ref_date"] = torch.tensor([[[2019, 182, 0]]], dtype=torch.int16).expand(B, 1, 3).contiguous().to(device)
+    return batch
+
+
+class PretrainLoop:
+    def __init__(self, model, batch_size: int, device, loss: str = "l2_norm", base_lr: float = 3e-5,
+                 betas=(0.9, 0.99), weight_decay: float = 0.01, total_steps: int = 1000, world_size: int = 1,
+                 final_factor: float = 1e7, bucket_mb: int = 64) -> None:
+        self.engine = model.engine(batch_size, device, loss=loss)
+        lr = scaled_lr(base_lr, batch_size, 1, 1, world_size)
+        self.sched = OneCycle(lr, max(total_steps, 2), pct_start=0.2, div_factor=1000.0,
+                              final_div_factor=final_factor / 1000.0)
+        self.opt = FusedAdamW(self.engine, lr, betas=betas, weight_decay=weight_decay)
+        self.sync = GradSync(self.engine.store.grad, bucket_bytes=bucket_mb << 20) if world_size > 1 else None
+        if self.sync is not None:
+            self.engine.grad_hook = self.sync.ready
+        self.it = 0
+
+    def step(self, batch: dict) -> torch.Tensor:
+        eng = self.engine
+        loss = eng.forward(batch)
+        eng.zero_grad()
+        scale = 1.0
+        if self.sync is not None:
+            self.sync.begin()
+        eng.backward()
+        if self.sync is not None:
+            scale = self.sync.finish()
+        self.opt.step(lr=self.sched.lr(self.it), grad_scale=scale)
+        self.it += 1
+        return loss
+
+
+def fit(module, batches, device, steps: int, **kw) -> list[float]:
+    """Tiny driver: ``module`` is an :class:`~maestro_amd.train.model.SSLModule`; returns the per-step losses."""
+    first = next(iter(module.dataset.inputs))
+    it = iter(batches)
+    batch = next(it)
+    loop = PretrainLoop(module.model, batch[first].shape[0], device, loss=module.loss_name, total_steps=steps, **kw)
+    losses = []
+    for _ in range(steps):
+        losses.append(float(loop.step(batch)))
+        batch = next(it, batch)
+    return losses

@@ -44,13 +44,15 @@ def test_layernorm_fwd_bwd(dev, dim, B, n, xL, xoff, yL, yoff, out_f32):
     dres = _rand(B, xL, dim, seed=5).to(dev)
     dx = torch.zeros(B, xL, dim, device=dev)
     dxb = torch.zeros(B, xL, dim, device=dev, dtype=torch.bfloat16)
-    dg, db = torch.zeros(dim, device=dev), torch.zeros(dim, device=dev)
-    hip.layernorm_bwd(dy_in, yL, yoff, x, xL, xoff, gamma, mean, rstd, dres, dx, dxb, dg, db, B, n, dim)
+    dg, db, dc = torch.zeros(dim, device=dev), torch.zeros(dim, device=dev), torch.ones(dim, device=dev)
+    ws = torch.zeros(hip.layernorm_bwd_workspace(B * n, dim), device=dev)
+    hip.layernorm_bwd(dy_in, yL, yoff, x, xL, xoff, gamma, mean, rstd, dres, dx, dxb, dg, db, dc, ws, B, n, dim)
     want.backward(dy_in[:, yoff:yoff + n].float())
     ref_dx = xs.grad + dres[:, xoff:xoff + n]
     assert (dx[:, xoff:xoff + n] - ref_dx).abs().max() < 2e-4
     assert (dxb[:, xoff:xoff + n].float() - ref_dx).abs().max() < 3e-2
     assert (dg - g_ref.grad).abs().max() < 2e-3 and (db - b_ref.grad).abs().max() < 2e-3
+    assert (dc - (1 + ref_dx.sum((0, 1)))).abs().max() < 2e-3
 
 
 # ----------------------------------------------------------------------------------------------- attention
