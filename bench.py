@@ -97,6 +97,7 @@ def main() -> None:
     ap.add_argument("--loss", default="l2_norm")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--shapes", action="store_true", help="print per-shape kernel times to stderr (diagnostic)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -125,18 +126,25 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 3)):   # >= 3 so the launch segments are captured into hipGraphs before timing
         loop.step(batch)
-    timer = None if args.no_kernel_timing else hip.KernelTimer()
     sync()
     t0 = time.perf_counter()
-    if timer is not None:
-        hip.set_kernel_timer(timer)
     for _ in range(args.steps):
         loss = loop.step(batch)
-    hip.set_kernel_timer(None)
     sync()
     elapsed = time.perf_counter() - t0
+    # Roofline leg: the same steps once more with HIP events around every MFMA-kernel launch on its stream (event
+    # pairs cannot be recorded inside a captured graph, so these steps are launched eagerly; kernels are identical).
+    timer = None if args.no_kernel_timing else hip.KernelTimer()
+    if timer is not None:
+        loop.engine.multi_stream = False   # one kernel at a time, so each event pair brackets exactly one launch
+        hip.set_kernel_timer(timer)
+        for _ in range(args.steps):
+            loop.step(batch)
+        hip.set_kernel_timer(None)
+        loop.engine.multi_stream = True
+        sync()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -160,7 +168,11 @@ def main() -> None:
         }
         if timer is not None:
             out["roofline"] = timer.roofline(MFMA_PEAK_TFLOPS)
+            out["roofline"]["measured_over"] = f"{args.steps} eagerly launched single-stream steps right after the timed region"
             out["kernel_times_ms_per_step"] = timer.summary(args.steps)
+        if timer is not None and args.shapes:
+            for ms, kind, shape, n, tf in timer.by_shape(args.steps)[:40]:
+                print(f"{ms:8.3f} ms/step {kind:18s} {str(shape):26s} x{n:3d}/step {tf:7.1f} TFLOP/s", file=sys.stderr)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
         print(json.dumps(out), flush=True)

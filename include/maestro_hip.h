@@ -33,7 +33,8 @@ int mh_version(void);
  * flags: bit0 out_f32 (else bf16) | bit1 +bias[N] | bit2 GELU(erf) (aux_out, if given, receives the bf16
  *        pre-activation) | bit3 += res[M,N] f32 (ldr) | bit4 *= gelu'(aux_in[M,N] bf16) | bit5 atomic accumulate
  *        into C (f32 only; split-K is applied automatically for layout 2).
- * Requirements: K % 8 == 0, lda/ldb % 8 == 0, N % 4 == 0, ldc % 4 == 0, 16-byte aligned bases. */
+ * Requirements: K % 8 == 0 (layouts 0/1), lda/ldb % 8 == 0, N % 4 == 0 and ldc % 4 == 0 (f32 out) or % 8 (bf16 out,
+ * aux), 16-byte aligned bases; residual needs f32 output, GELU/GELU' need bf16 output. */
 #define MH_GEMM_OUT_F32 1
 #define MH_GEMM_BIAS 2
 #define MH_GEMM_GELU 4

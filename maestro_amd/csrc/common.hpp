@@ -61,10 +61,30 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// GELU (exact-erf form of nn.GELU) and its derivative with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far
+// below the bf16 output resolution): one v_exp + one v_rcp + 5 FMAs instead of the ~40-instruction erff.  The
+// exp(-x^2/2) factor is shared between the CDF and the PDF term of the derivative.
+__device__ __forceinline__ void gelu_cdf_pdf(float x, float& cdf, float& pdf) {
+    const float ax = fabsf(x) * 0.70710678118654752f;                  // |x| / sqrt(2)
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);  // exp(-x^2/2)
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float erf_abs = 1.f - poly * t * e;                          // erf(|x|/sqrt2)
+    cdf = 0.5f * (1.f + copysignf(erf_abs, x));
+    pdf = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    float cdf, pdf;
+    gelu_cdf_pdf(x, cdf, pdf);
+    return x * cdf;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    float cdf, pdf;
+    gelu_cdf_pdf(x, cdf, pdf);
     return cdf + x * pdf;
 }
 

@@ -102,8 +102,16 @@ template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // A0 A1 B0 B1
     const int nwg = p.tiles_m * p.tiles_n;
+    // XCD-aware + grouped rasterisation: every XCD gets a contiguous run of ids, and ids walk GROUP_M m-tiles before
+    // moving to the next n-tile, so the ~64 workgroups co-resident on one XCD (32 CUs x 2) cover an 8x8 super-tile:
+    // 8 A stripes + 8 B panels (~3 MB at K=768) stay in that XCD's 4 MB L2 instead of a whole B matrix.
     const int id = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * p.tiles_n;
+    const int group = id / per_group, in_group = id - group * per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int tile_m = first_m + in_group % gsz, tile_n = in_group / gsz;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = blockIdx.y * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -181,44 +189,66 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
         return;
     }
 
+    // Epilogue.  Each wave transposes its 64x64 fp32 tile through a private LDS region (two passes of 32 rows, 68-float
+    // row pitch: conflict-free ds_write_b128 / ds_read_b128) so that the bias / residual / aux reads and the C / aux
+    // writes are done in ROW-MAJOR lane order: 8 lanes cover one 128-byte row segment with 16-byte accesses.
     const bool out_f32 = p.flags & MH_GEMM_OUT_F32;
+    float* st = reinterpret_cast<float*>(smem) + w * (32 * 68);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm + 16 * i + lm;
-        if (m >= p.M) continue;
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn + 16 * j + 4 * g;
-            if (n >= p.N) continue;
-            f32x4 v = acc[j][i];
-            if (p.flags & MH_GEMM_BIAS) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-                v += b;
-            }
-            if (p.flags & MH_GEMM_GELU) {
-                if (p.aux_out) {
-                    u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                    *reinterpret_cast<u32x2*>(p.aux_out + (size_t)m * p.ldaux + n) = pk;
+        for (int i = 2 * half; i < 2 * half + 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(st + (16 * (i - 2 * half) + lm) * 68 + 16 * j + 4 * g) = acc[j][i];
+        if (out_f32) {
+            const int c = (l & 15) * 4, n = n0 + wn + c;
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int r = pass * 4 + (l >> 4), m = m0 + wm + 32 * half + r;
+                f32x4 v = *reinterpret_cast<const f32x4*>(st + r * 68 + c);
+                if (m < p.M && n < p.N) {
+                    if (p.flags & MH_GEMM_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (p.flags & MH_GEMM_RESIDUAL) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n);
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
                 }
+            }
+        } else {
+            const int c = (l & 7) * 8, n = n0 + wn + c;
+            f32x4 b_lo = {0, 0, 0, 0}, b_hi = {0, 0, 0, 0};
+            if ((p.flags & MH_GEMM_BIAS) && n < p.N) {
+                b_lo = *reinterpret_cast<const f32x4*>(p.bias + n);
+                b_hi = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            }
-            if (p.flags & MH_GEMM_DGELU) {
-                const u32x2 pk = *reinterpret_cast<const u32x2*>(p.aux_in + (size_t)m * p.ldaux + n);
-                v[0] *= gelu_erf_grad(__uint_as_float(pk[0] << 16));
-                v[1] *= gelu_erf_grad(__uint_as_float(pk[0] & 0xffff0000u));
-                v[2] *= gelu_erf_grad(__uint_as_float(pk[1] << 16));
-                v[3] *= gelu_erf_grad(__uint_as_float(pk[1] & 0xffff0000u));
-            }
-            if (p.flags & MH_GEMM_RESIDUAL) {
-                const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n);
-                v += r4;
-            }
-            if (out_f32) {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
-            } else {
-                u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
+            for (int pass = 0; pass < 4; ++pass) {
+                const int r = pass * 8 + (l >> 3), m = m0 + wm + 32 * half + r;
+                f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * 68 + c);
+                f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * 68 + c + 4);
+                if (m < p.M && n < p.N) {
+                    lo += b_lo; hi += b_hi;
+                    if (p.flags & MH_GEMM_GELU) {
+                        if (p.aux_out) {
+                            u32x4 pk = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+                            *reinterpret_cast<u32x4*>(p.aux_out + (size_t)m * p.ldaux + n) = pk;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { lo[e] = gelu_erf(lo[e]); hi[e] = gelu_erf(hi[e]); }
+                    }
+                    if (p.flags & MH_GEMM_DGELU) {
+                        const u32x4 pk = *reinterpret_cast<const u32x4*>(p.aux_in + (size_t)m * p.ldaux + n);
+                        lo[0] *= gelu_erf_grad(__uint_as_float(pk[0] << 16));
+                        lo[1] *= gelu_erf_grad(__uint_as_float(pk[0] & 0xffff0000u));
+                        lo[2] *= gelu_erf_grad(__uint_as_float(pk[1] << 16));
+                        lo[3] *= gelu_erf_grad(__uint_as_float(pk[1] & 0xffff0000u));
+                        hi[0] *= gelu_erf_grad(__uint_as_float(pk[2] << 16));
+                        hi[1] *= gelu_erf_grad(__uint_as_float(pk[2] & 0xffff0000u));
+                        hi[2] *= gelu_erf_grad(__uint_as_float(pk[3] << 16));
+                        hi[3] *= gelu_erf_grad(__uint_as_float(pk[3] & 0xffff0000u));
+                    }
+                    u32x4 pk = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
+                }
             }
         }
     }
@@ -234,6 +264,9 @@ extern "C" int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int 
     MH_CHECK_ARG(A && B && C, "mh_gemm_bf16: null operand");
     MH_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0, "mh_gemm_bf16: lda/ldb must be multiples of 8 (%d, %d)", lda, ldb);
     MH_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0, "mh_gemm_bf16: N and ldc must be multiples of 4 (%d, %d)", N, ldc);
+    MH_CHECK_ARG((flags & MH_GEMM_OUT_F32) || (N % 8 == 0 && ldc % 8 == 0), "mh_gemm_bf16: bf16 output needs N, ldc %% 8 == 0");
+    MH_CHECK_ARG((flags & MH_GEMM_OUT_F32) || !(flags & MH_GEMM_RESIDUAL), "mh_gemm_bf16: residual epilogue needs f32 output");
+    MH_CHECK_ARG(!(flags & MH_GEMM_OUT_F32) || !(flags & (MH_GEMM_GELU | MH_GEMM_DGELU)), "mh_gemm_bf16: GELU epilogues need bf16 output");
     MH_CHECK_ARG(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 == 0, "mh_gemm_bf16: bases must be 16-B aligned");
     if (layout == 2) {
         MH_CHECK_ARG(M % 8 == 0 && N % 8 == 0, "mh_gemm_bf16: TN needs M, N multiples of 8 (%d, %d)", M, N);
@@ -243,8 +276,8 @@ extern "C" int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int 
     }
     MH_CHECK_ARG(!(flags & MH_GEMM_BIAS) || bias, "mh_gemm_bf16: bias flag without pointer");
     MH_CHECK_ARG(!(flags & MH_GEMM_RESIDUAL) || (res && ldr % 4 == 0), "mh_gemm_bf16: residual needs pointer, ldr%%4==0");
-    MH_CHECK_ARG(!(flags & MH_GEMM_DGELU) || (aux_in && ldaux % 4 == 0), "mh_gemm_bf16: dgelu needs aux_in");
-    MH_CHECK_ARG(!(flags & MH_GEMM_GELU) || !aux_out || ldaux % 4 == 0, "mh_gemm_bf16: ldaux %% 4");
+    MH_CHECK_ARG(!(flags & MH_GEMM_DGELU) || (aux_in && ldaux % 8 == 0), "mh_gemm_bf16: dgelu needs aux_in, ldaux %% 8 == 0");
+    MH_CHECK_ARG(!(flags & MH_GEMM_GELU) || !aux_out || ldaux % 8 == 0, "mh_gemm_bf16: ldaux %% 8");
     MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || (flags & MH_GEMM_OUT_F32), "mh_gemm_bf16: atomic needs f32 output");
     MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || !(flags & ~(MH_GEMM_ATOMIC | MH_GEMM_OUT_F32)),
                  "mh_gemm_bf16: atomic accumulate excludes other epilogues");

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void unpack_rows_add_kernel(const float* __res
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)E * K) return;
     const int e = i / K, k = i - (long)e * K;
-    dst[i] += src[(size_t)e * Kpad + k];
+    atomicAdd(dst + i, src[(size_t)e * Kpad + k]);  // shared patch-embed weights may be updated from parallel streams
 }
 
 // torch.optim.AdamW step (decoupled weight decay, bias correction), 4 elements per thread, grid-stride free.

@@ -24,6 +24,7 @@ from maestro_amd import hip
 from maestro_amd.layers.utils import draw_struct_masks
 
 F32, BF16, I32, U8 = torch.float32, torch.bfloat16, torch.int32, torch.uint8
+_NEVER = object()
 ALIGN = 64  # elements; keeps every parameter view 256-byte aligned
 
 
@@ -104,6 +105,7 @@ class Stack:
         self.dxa16, self.dxb16 = e(M, dim, dt=BF16), e(M, dim, dt=BF16)
         self.dh, self.dh2 = e(M, mlp, dt=BF16), e(M, dim, dt=BF16)
         self.do, self.dqkv, self.delta = e(M, self.inner, dt=BF16), e(M, 3 * self.inner, dt=BF16), e(Bn * self.H * N)
+        self.ln_ws = e(max(1, hip.layernorm_bwd_workspace(M, dim)))  # private: stacks of different groups run concurrently
 
     @property
     def x0(self):
@@ -155,7 +157,7 @@ class Stack:
             hip.colsum(self.dh, ps.g(fc1.bias), M, mlp, mlp)
             proj = attn.to_out[0]
             hip.layernorm_bwd(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16,
-                              ps.g(ln2.weight), ps.g(ln2.bias), ps.g(proj.bias), eng.ln_ws, 1, M, dim)
+                              ps.g(ln2.weight), ps.g(ln2.bias), ps.g(proj.bias), self.ln_ws, 1, M, dim)
             # ---- attention: x_mid = x_in + proj(attn(qkv(LN1(x_in))))
             nxt, nxt16 = (self.dxa, self.dxa16) if mid is not self.dxa else (self.dxb, self.dxb16)
             hip.gemm(hip.GEMM_NN, M, inner, dim, mid16, dim, ps.h(proj.weight), inner, self.do, inner)
@@ -166,7 +168,7 @@ class Stack:
             hip.gemm(hip.GEMM_TN, 3 * inner, dim, M, self.dqkv, 3 * inner, s["h1"], dim, ps.g(attn.to_qkv.weight), dim, AT)
             prev_fc2_bias = ps.g(self.t.layers[l - 1][1].net[4].bias) if l > 0 else None  # = colsum(dx_out of layer l-1)
             hip.layernorm_bwd(self.dh2, M, 0, x_in, M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid, nxt, nxt16,
-                              ps.g(attn.norm.weight), ps.g(attn.norm.bias), prev_fc2_bias, eng.ln_ws, 1, M, dim)
+                              ps.g(attn.norm.weight), ps.g(attn.norm.bias), prev_fc2_bias, self.ln_ws, 1, M, dim)
             cur, cur16 = nxt, nxt16
             eng._grads_ready(self.t.layers[l])
         return cur
@@ -189,6 +191,10 @@ class MAEEngine:
             raise NotImplementedError("embed_dim == decoder_dim (Identity enc_to_dec) is not built")
         self.E, self.Dd = m.embed_dim, m.decoder_dim
         self.grad_hook = None  # callable(lo, hi) invoked when grad[lo:hi] is final (DDP bucket launch)
+        self.use_graphs = True      # capture launch segments into hipGraphs once input addresses repeat
+        self.multi_stream = True    # independent groups on parallel HIP streams
+        self._graphs, self._seen, self._ready_spans = {}, {}, []
+        self.side_streams = [torch.cuda.Stream(device=device) for _ in range(max(0, len(model.group_specs) - 1))]
         B = batch_size  # noqa: N806
         fold = m.fusion_mode in ("shared", "monotemp")
         self.mods, self.groups = m.mod_specs, list(m.group_specs.values())
@@ -260,8 +266,9 @@ class MAEEngine:
             self.joint = Stack(self, m.encoder_inter, self.B, m.joint_N, "joint")
         else:
             self.joint = None
-        stacks = list(self.enc.values()) + list(self.dec.values()) + ([self.joint] if self.joint is not None else [])
-        self.ln_ws = e(max(hip.layernorm_bwd_workspace(st.M, st.dim) for st in stacks))
+        for g in self.groups:  # per-group LN-backward workspace (final norms; groups run on parallel streams)
+            self.gb[g.name]["ln_ws"] = e(max(hip.layernorm_bwd_workspace(g.Beff * g.L, Dd),
+                                             hip.layernorm_bwd_workspace(g.Beff * g.N, E)))
         self.loss_acc = z(1)
         tot_w = sum(s.Dates * s.L for s in self.mods.values())
         self.loss_w = {n: (s.Dates * s.L) / tot_w for n, s in self.mods.items()}  # weight = D*H*W (model.py:239)
@@ -272,10 +279,10 @@ class MAEEngine:
             hip.pack_rows_bf16(b["pe"].conv.weight, b["w_conv16"], self.E, s.K, s.Kpad)
 
     def _grads_ready(self, module) -> None:
-        if self.grad_hook is not None:
-            ps = list(module.parameters())
-            if ps:
-                self.grad_hook(*self.store.span(ps))
+        """Record that the gradient slice of ``module`` is final (handed to ``grad_hook`` after the segment)."""
+        ps = list(module.parameters())
+        if ps:
+            self._ready_spans.append(self.store.span(ps))
 
     # ------------------------------------------------------------------------------------------ RNG (host)
     def draw_masks(self, generator=None):
@@ -284,175 +291,262 @@ class MAEEngine:
         noise = {g.name: torch.rand((g.Beff, g.L), generator=generator) for g in self.groups}
         return noise, struct
 
+    # ------------------------------------------------------------------------------------------ streams / graphs
+    def _run_parallel(self, fns) -> None:
+        if len(fns) == 1 or not self.multi_stream:
+            for fn in fns:
+                fn()
+            return
+        main = torch.cuda.current_stream()
+        sides = self.side_streams[: len(fns) - 1]
+        for side in sides:
+            side.wait_stream(main)
+        fns[0]()
+        for side, fn in zip(sides, fns[1:]):
+            with torch.cuda.stream(side):
+                fn()
+        for side in sides:
+            main.wait_stream(side)
+
+    def _segment(self, name: str, key, fn) -> None:
+        """Run one launch segment: eagerly, or as a captured hipGraph replay when the input addresses are unchanged."""
+        if not self.use_graphs or hip.kernel_timer_active():
+            self._ready_spans = []
+            fn()
+            self._flush_ready(self._ready_spans)
+            return
+        entry = self._graphs.get(name)
+        if entry is not None and entry["key"] == key:
+            entry["graph"].replay()
+            self._flush_ready(entry["spans"])
+            return
+        seen = self._seen.get(name, _NEVER)
+        self._ready_spans = []
+        if seen == key:  # second time with the same addresses: capture (the first eager run warmed everything up)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fn()
+            self._graphs[name] = {"key": key, "graph": graph, "spans": list(self._ready_spans)}
+            graph.replay()
+        else:
+            self._seen[name] = key
+            fn()
+        self._flush_ready(self._ready_spans)
+
+    def _flush_ready(self, spans) -> None:
+        if self.grad_hook is not None:
+            for lo, hi in spans:
+                self.grad_hook(lo, hi)
+
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, batch: dict, noise: dict | None = None, struct: dict | None = None) -> torch.Tensor:
         """Runs the forward pass + loss; returns the loss as a 1-element device tensor (no host sync)."""
-        m, E, Dd = self.model, self.E, self.Dd  # noqa: N806
         if self.store.refresh_half():
             self._pack_conv_weights()
         if noise is None or struct is None:
             n2, s2 = self.draw_masks()
             noise = noise if noise is not None else n2
             struct = struct if struct is not None else s2
-        self.loss_acc.zero_()
-        ref_date = batch["ref_date"]
-        # ---- embed: patchify -> conv GEMM -> GroupNorm + encodings into the group sequence
-        for g in self.groups:
+        for g in self.groups:  # host -> pinned -> device (outside any graph)
             gbuf = self.gb[g.name]
-            for s in g.mods:
-                b = self.mb[s.name]
-                img = batch[s.name]
-                if tuple(img.shape[-2:]) != (s.S, s.S):
-                    raise NotImplementedError("input rasters must already be at image_size (resize: SURVEY §8(f) next)")
-                if img.dtype != F32 or not img.is_contiguous():
-                    raise ValueError(f"batch[{s.name!r}] must be a contiguous float32 tensor")
-                BD = s.Beff * s.D  # noqa: N806
-                hip.patchify(img, b["cols"], b["target"], BD, s.C, s.S, s.P, s.Kpad, b["norm_bands"], len(s.norm_bands),
-                             self.normalise, s.rescale_elev)
-                dates = batch[f"{s.name}_dates"]
-                fold = s.D != s.Dates
-                if fold:   # dates folded into the batch: one date row per sequence
-                    hip.date_features(dates, ref_date, gbuf["dates"].view(self.B, s.Dates, 8), self.B, s.Dates, s.Dates, 0,
-                                      m.fac_date_enc)
-                else:
-                    hip.date_features(dates, ref_date, gbuf["dates"], self.B, s.D, gbuf["n_dates"], s.date_off, m.fac_date_enc)
-                pe = b["pe"]
-                T = s.Beff * s.n_tok  # noqa: N806
-                hip.gemm(hip.GEMM_NT, T, E, s.Kpad, b["cols"], s.Kpad, b["w_conv16"], s.Kpad, b["yconv"], E,
-                         hip.OUT_F32 | hip.BIAS, bias=pe.conv.bias)
-                hip.groupnorm_stats(b["yconv"], b["gn_partial"], b["gn_stats"], BD, s.L, E)
-                hip.embed_finish(b["yconv"], b["gn_stats"], pe.norm.weight, pe.norm.bias, b["pos_enc"], gbuf["dates"],
-                                 gbuf["n_dates"], s.date_off, gbuf["xg"], s.Beff, s.D, s.L, E, s.tok_off, g.L)
-        # ---- mask + gather + per-group encoder
-        for g in self.groups:
-            gbuf, st = self.gb[g.name], self.enc[g.name]
             gbuf["noise_h"].copy_(noise[g.name])
             gbuf["struct_h"].copy_(struct[g.name].reshape(g.Beff, g.L).to(U8))
             gbuf["noise"].copy_(gbuf["noise_h"], non_blocking=True)
             gbuf["struct"].copy_(gbuf["struct_h"], non_blocking=True)
-            hip.mask_select(gbuf["noise"], gbuf["struct"], gbuf["vis"], gbuf["msk"], gbuf["inv"], gbuf["mask"], g.Beff, g.L, g.k)
-            hip.gather_rows(gbuf["xg"], gbuf["vis"], st.x0, g.Beff, g.L, g.N, E, g.N, 0)
-            st.forward()
-        # ---- joint encoder over the concatenated visible tokens, then final LN per group -> bf16
-        for g in self.groups:
-            gbuf, st = self.gb[g.name], self.enc[g.name]
-            nrm = st.t.norm
-            if self.joint is not None:
-                hip.layernorm_fwd(st.x_last, g.N, 0, nrm.weight, nrm.bias, self.joint.x0, m.joint_N, g.joint_off,
-                                  gbuf["mean_e"], gbuf["rstd_e"], g.Beff, g.N, E)
-            else:
-                hip.layernorm_fwd(st.x_last, g.N, 0, nrm.weight, nrm.bias, gbuf["henc"], g.N, 0, gbuf["mean_e"],
-                                  gbuf["rstd_e"], g.Beff, g.N, E)
+        for s in self.mods.values():
+            img = batch[s.name]
+            if tuple(img.shape[-2:]) != (s.S, s.S):
+                raise NotImplementedError("input rasters must already be at image_size (resize: SURVEY §8(f) next)")
+            if img.dtype != F32 or not img.is_contiguous() or not img.is_cuda:
+                raise ValueError(f"batch[{s.name!r}] must be a contiguous float32 GPU tensor")
+            d = batch[f"{s.name}_dates"]
+            if d.dtype != torch.int16 or not d.is_contiguous():
+                raise ValueError(f"batch['{s.name}_dates'] must be a contiguous int16 tensor [B, D, 3]")
+        key = self._cur_key = tuple(batch[k].data_ptr() for k in sorted(batch) if isinstance(batch[k], torch.Tensor))
+        self._segment("forward", key, lambda: self._forward_launches(batch))
+        return self.loss_acc
+
+    def _forward_launches(self, batch: dict) -> None:
+        m, E, Dd = self.model, self.E, self.Dd  # noqa: N806
+        self.loss_acc.zero_()
+        ref_date = batch["ref_date"]
+
+        def head(g):
+            def run():
+                gbuf, st = self.gb[g.name], self.enc[g.name]
+                # ---- embed: patchify -> conv GEMM -> GroupNorm + encodings into the group sequence
+                for s in g.mods:
+                    b = self.mb[s.name]
+                    BD = s.Beff * s.D  # noqa: N806
+                    hip.patchify(batch[s.name], b["cols"], b["target"], BD, s.C, s.S, s.P, s.Kpad, b["norm_bands"],
+                                 len(s.norm_bands), self.normalise, s.rescale_elev)
+                    dates = batch[f"{s.name}_dates"]
+                    if s.D != s.Dates:   # dates folded into the batch: one date row per sequence
+                        hip.date_features(dates, ref_date, gbuf["dates"].view(self.B, s.Dates, 8), self.B, s.Dates, s.Dates,
+                                          0, m.fac_date_enc)
+                    else:
+                        hip.date_features(dates, ref_date, gbuf["dates"], self.B, s.D, gbuf["n_dates"], s.date_off,
+                                          m.fac_date_enc)
+                    pe = b["pe"]
+                    T = s.Beff * s.n_tok  # noqa: N806
+                    hip.gemm(hip.GEMM_NT, T, E, s.Kpad, b["cols"], s.Kpad, b["w_conv16"], s.Kpad, b["yconv"], E,
+                             hip.OUT_F32 | hip.BIAS, bias=pe.conv.bias)
+                    hip.groupnorm_stats(b["yconv"], b["gn_partial"], b["gn_stats"], BD, s.L, E)
+                    hip.embed_finish(b["yconv"], b["gn_stats"], pe.norm.weight, pe.norm.bias, b["pos_enc"], gbuf["dates"],
+                                     gbuf["n_dates"], s.date_off, gbuf["xg"], s.Beff, s.D, s.L, E, s.tok_off, g.L)
+                # ---- mask + gather + per-group encoder + its final LN (into the joint sequence, or bf16 for enc_to_dec)
+                hip.mask_select(gbuf["noise"], gbuf["struct"], gbuf["vis"], gbuf["msk"], gbuf["inv"], gbuf["mask"], g.Beff,
+                                g.L, g.k)
+                hip.gather_rows(gbuf["xg"], gbuf["vis"], st.x0, g.Beff, g.L, g.N, E, g.N, 0)
+                st.forward()
+                nrm = st.t.norm
+                if self.joint is not None:
+                    hip.layernorm_fwd(st.x_last, g.N, 0, nrm.weight, nrm.bias, self.joint.x0, m.joint_N, g.joint_off,
+                                      gbuf["mean_e"], gbuf["rstd_e"], g.Beff, g.N, E)
+                else:
+                    hip.layernorm_fwd(st.x_last, g.N, 0, nrm.weight, nrm.bias, gbuf["henc"], g.N, 0, gbuf["mean_e"],
+                                      gbuf["rstd_e"], g.Beff, g.N, E)
+            return run
+
+        def tail(g):
+            def run():
+                gbuf, st = self.gb[g.name], self.dec[g.name]
+                if self.joint is not None:
+                    nrm = self.joint.t.norm
+                    hip.layernorm_fwd(self.joint.x_last, m.joint_N, g.joint_off, nrm.weight, nrm.bias, gbuf["henc"], g.N, 0,
+                                      gbuf["mean_j"], gbuf["rstd_j"], g.Beff, g.N, E)
+                lin = m.enc_to_dec[g.model]
+                M = g.Beff * g.N  # noqa: N806
+                hip.gemm(hip.GEMM_NT, M, Dd, E, gbuf["henc"], E, self.store.h(lin.weight), E, gbuf["y_e2d"], Dd,
+                         hip.OUT_F32 | hip.BIAS, bias=lin.bias)
+                for s in g.mods:
+                    gbuf["tok_table"][s.slot].copy_(m.mask_token[s.name].view(-1))
+                hip.unmask_assemble(gbuf["y_e2d"], gbuf["inv"], gbuf["tok_table"], gbuf["tok_slot"], gbuf["pos_dec"],
+                                    gbuf["dates"], gbuf["date_row"], gbuf["n_dates"], st.x0, g.Beff, g.L, g.N, Dd)
+                st.forward()
+                nrm = st.t.norm
+                for s in g.mods:
+                    b = self.mb[s.name]
+                    T = s.Beff * s.n_tok  # noqa: N806
+                    conv = m.embed_to_rec[s.embed].pixelify_bands[0].conv
+                    hip.layernorm_fwd(st.x_last, g.L, s.tok_off, nrm.weight, nrm.bias, b["hdec"], s.n_tok, 0, b["mean_f"],
+                                      b["rstd_f"], s.Beff, s.n_tok, Dd)
+                    hip.gemm(hip.GEMM_NT, T, s.K, Dd, b["hdec"], Dd, self.store.h(conv.weight).view(s.K, Dd), Dd, b["rec"],
+                             s.K, hip.OUT_F32 | hip.BIAS, bias=conv.bias)
+                    hip.count_masked(gbuf["mask"], g.Beff, g.L, s.tok_off, s.tok_off + s.n_tok, b["cnt"])
+                    hip.masked_loss(b["rec"], b["target"], gbuf["mask"], b["cnt"], self.loss_w[s.name], self.loss_acc,
+                                    b["drec"], s.Beff, s.n_tok, g.L, s.tok_off, s.K, self.p_loss)
+            return run
+
+        self._run_parallel([head(g) for g in self.groups])
         if self.joint is not None:
             self.joint.forward()
-            nrm = self.joint.t.norm
-            for g in self.groups:
-                gbuf = self.gb[g.name]
-                hip.layernorm_fwd(self.joint.x_last, m.joint_N, g.joint_off, nrm.weight, nrm.bias, gbuf["henc"], g.N, 0,
-                                  gbuf["mean_j"], gbuf["rstd_j"], g.Beff, g.N, E)
-        # ---- enc_to_dec, unmask + decoder encodings, decoder, pixelify, loss
-        for g in self.groups:
-            gbuf, st = self.gb[g.name], self.dec[g.name]
-            lin = m.enc_to_dec[g.model]
-            M = g.Beff * g.N  # noqa: N806
-            hip.gemm(hip.GEMM_NT, M, Dd, E, gbuf["henc"], E, self.store.h(lin.weight), E, gbuf["y_e2d"], Dd,
-                     hip.OUT_F32 | hip.BIAS, bias=lin.bias)
-            for s in g.mods:
-                gbuf["tok_table"][s.slot].copy_(m.mask_token[s.name].view(-1))
-            hip.unmask_assemble(gbuf["y_e2d"], gbuf["inv"], gbuf["tok_table"], gbuf["tok_slot"], gbuf["pos_dec"],
-                                gbuf["dates"], gbuf["date_row"], gbuf["n_dates"], st.x0, g.Beff, g.L, g.N, Dd)
-            st.forward()
-            nrm = st.t.norm
-            for s in g.mods:
-                b = self.mb[s.name]
-                T = s.Beff * s.n_tok  # noqa: N806
-                conv = m.embed_to_rec[s.embed].pixelify_bands[0].conv
-                hip.layernorm_fwd(st.x_last, g.L, s.tok_off, nrm.weight, nrm.bias, b["hdec"], s.n_tok, 0, b["mean_f"],
-                                  b["rstd_f"], s.Beff, s.n_tok, Dd)
-                hip.gemm(hip.GEMM_NT, T, s.K, Dd, b["hdec"], Dd, self.store.h(conv.weight).view(s.K, Dd), Dd, b["rec"], s.K,
-                         hip.OUT_F32 | hip.BIAS, bias=conv.bias)
-                hip.count_masked(gbuf["mask"], g.Beff, g.L, s.tok_off, s.tok_off + s.n_tok, b["cnt"])
-                hip.masked_loss(b["rec"], b["target"], gbuf["mask"], b["cnt"], self.loss_w[s.name], self.loss_acc, b["drec"],
-                                s.Beff, s.n_tok, g.L, s.tok_off, s.K, self.p_loss)
-        return self.loss_acc
+        self._run_parallel([tail(g) for g in self.groups])
 
     # ------------------------------------------------------------------------------------------ backward
     def zero_grad(self) -> None:
         self.store.grad.zero_()
 
     def backward(self, grad_scale: float = 1.0) -> None:
-        """Backward of the last ``forward`` (d loss = 1); accumulates into the flat grad buffer (zero it first)."""
+        """Backward of the last ``forward`` (d loss = 1); accumulates into the flat grad buffer (zero it first).
+
+        Three launch segments (decoder side, joint encoder, encoder/embedding side); after each one the gradient
+        slices it completed are handed to ``grad_hook`` (bucketed RCCL all-reduce overlapping the next segment).
+        """
         if grad_scale != 1.0:
             raise NotImplementedError("loss scaling is not needed for bf16 (SURVEY §8(f) AMP row)")
+        key = getattr(self, "_cur_key", None)
+        self._segment("bwd_dec", key, self._bwd_decoder_side)
+        if self.joint is not None:
+            self._segment("bwd_joint", key, self._bwd_joint)
+        self._segment("bwd_enc", key, self._bwd_encoder_side)
+
+    def _bwd_decoder_side(self) -> None:
         m, E, Dd, ps = self.model, self.E, self.Dd, self.store  # noqa: N806
         AT = hip.OUT_F32 | hip.ATOMIC  # noqa: N806
-        for g in reversed(self.groups):
-            gbuf, st = self.gb[g.name], self.dec[g.name]
-            nrm = st.t.norm
-            dx, dx16 = st.dxa, st.dxa16          # gradient w.r.t. the decoder's last residual
-            for s in g.mods:
-                b = self.mb[s.name]
-                T = s.Beff * s.n_tok  # noqa: N806
-                conv = m.embed_to_rec[s.embed].pixelify_bands[0].conv
-                w16 = ps.h(conv.weight).view(s.K, Dd)
-                hip.gemm(hip.GEMM_NN, T, Dd, s.K, b["drec"], s.K, w16, Dd, b["dh"], Dd)
-                hip.gemm(hip.GEMM_TN, s.K, Dd, T, b["drec"], s.K, b["hdec"], Dd, ps.g(conv.weight).view(s.K, Dd), Dd, AT)
-                hip.colsum(b["drec"], ps.g(conv.bias), T, s.K, s.K)
-                hip.layernorm_bwd(b["dh"], s.n_tok, 0, st.x_last, g.L, s.tok_off, nrm.weight, b["mean_f"], b["rstd_f"], None,
-                                  dx, dx16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(), self.ln_ws, s.Beff,
-                                  s.n_tok, Dd)
-                self._grads_ready(m.embed_to_rec[s.embed])
-            dx0 = st.backward(dx, dx16)
-            self._grads_ready(nrm)
-            # unmask backward: visible rows -> enc_to_dec output grad; masked rows -> mask-token grads
-            hip.gather_rows(dx0, gbuf["vis"], gbuf["dy_e2d"], g.Beff, g.L, g.N, Dd, g.N, 0)
-            for s in g.mods:
-                hip.unmask_token_grad(dx0, gbuf["mask"], gbuf["tok_slot"], ps.g(m.mask_token[s.name]).view(-1), g.Beff, g.L,
-                                      Dd, s.slot, s.tok_off, s.tok_off + s.n_tok)
-            M = g.Beff * g.N  # noqa: N806
-            hip.cast_bf16(gbuf["dy_e2d"], gbuf["dy_e2d16"], M * Dd)
-            lin = m.enc_to_dec[g.model]
-            hip.gemm(hip.GEMM_NN, M, E, Dd, gbuf["dy_e2d16"], Dd, ps.h(lin.weight), E, gbuf["dhenc"], E)
-            hip.gemm(hip.GEMM_TN, Dd, E, M, gbuf["dy_e2d16"], Dd, gbuf["henc"], E, ps.g(lin.weight), E, AT)
-            hip.colsum(gbuf["dy_e2d16"], ps.g(lin.bias), M, Dd, Dd)
-            self._grads_ready(lin)
-        # ---- joint encoder
-        if self.joint is not None:
-            jt = self.joint
-            nrm = jt.t.norm
-            for g in self.groups:
-                gbuf = self.gb[g.name]
-                hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, jt.x_last, m.joint_N, g.joint_off, nrm.weight, gbuf["mean_j"],
-                                  gbuf["rstd_j"], None, jt.dxa, jt.dxa16, ps.g(nrm.weight), ps.g(nrm.bias),
-                                  jt.top_bias_grad(), self.ln_ws, g.Beff, g.N, E)
-            djoint = jt.backward(jt.dxa, jt.dxa16)
-            self._grads_ready(nrm)
-        for g in reversed(self.groups):
-            gbuf, st = self.gb[g.name], self.enc[g.name]
-            nrm = st.t.norm
-            if self.joint is not None:
-                hip.layernorm_bwd(djoint, m.joint_N, g.joint_off, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"],
-                                  gbuf["rstd_e"], None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias),
-                                  st.top_bias_grad(), self.ln_ws, g.Beff, g.N, E)
-            else:
-                hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"], gbuf["rstd_e"],
-                                  None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(), self.ln_ws,
-                                  g.Beff, g.N, E)
-            dx0 = st.backward(st.dxa, st.dxa16)
-            self._grads_ready(nrm)
-            # scatter to the full group sequence (masked tokens get zero), then patch-embed backward per modality
-            gbuf["dxg"].zero_()
-            hip.scatter_rows(dx0, gbuf["vis"], gbuf["dxg"], g.Beff, g.L, g.N, E, g.N, 0)
-            for s in g.mods:
-                b = self.mb[s.name]
-                pe = b["pe"]
-                T = s.Beff * s.n_tok  # noqa: N806
-                hip.embed_finish_bwd(gbuf["dxg"], b["yconv"], b["gn_stats"], pe.norm.weight, b["dyc"], ps.g(pe.norm.weight),
-                                     ps.g(pe.norm.bias), b["gn_sums"], s.Beff, s.D, s.L, E, s.tok_off, g.L)
-                b["dw_conv"].zero_()
-                hip.gemm(hip.GEMM_TN, E, s.Kpad, T, b["dyc"], E, b["cols"], s.Kpad, b["dw_conv"], s.Kpad, AT)
-                hip.unpack_rows_add(b["dw_conv"], ps.g(pe.conv.weight), E, s.K, s.Kpad)
-                hip.colsum(b["dyc"], ps.g(pe.conv.bias), T, E, E)
+
+        def side(g):
+            def run():
+                gbuf, st = self.gb[g.name], self.dec[g.name]
+                nrm = st.t.norm
+                dx, dx16 = st.dxa, st.dxa16          # gradient w.r.t. the decoder's last residual
+                for s in g.mods:
+                    b = self.mb[s.name]
+                    T = s.Beff * s.n_tok  # noqa: N806
+                    conv = m.embed_to_rec[s.embed].pixelify_bands[0].conv
+                    w16 = ps.h(conv.weight).view(s.K, Dd)
+                    hip.gemm(hip.GEMM_NN, T, Dd, s.K, b["drec"], s.K, w16, Dd, b["dh"], Dd)
+                    hip.gemm(hip.GEMM_TN, s.K, Dd, T, b["drec"], s.K, b["hdec"], Dd, ps.g(conv.weight).view(s.K, Dd), Dd, AT)
+                    hip.colsum(b["drec"], ps.g(conv.bias), T, s.K, s.K)
+                    hip.layernorm_bwd(b["dh"], s.n_tok, 0, st.x_last, g.L, s.tok_off, nrm.weight, b["mean_f"], b["rstd_f"],
+                                      None, dx, dx16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(), gbuf["ln_ws"],
+                                      s.Beff, s.n_tok, Dd)
+                    self._grads_ready(m.embed_to_rec[s.embed])
+                dx0 = st.backward(dx, dx16)
+                self._grads_ready(nrm)
+                # unmask backward: visible rows -> enc_to_dec output grad; masked rows -> mask-token grads
+                hip.gather_rows(dx0, gbuf["vis"], gbuf["dy_e2d"], g.Beff, g.L, g.N, Dd, g.N, 0)
+                for s in g.mods:
+                    hip.unmask_token_grad(dx0, gbuf["mask"], gbuf["tok_slot"], ps.g(m.mask_token[s.name]).view(-1), g.Beff,
+                                          g.L, Dd, s.slot, s.tok_off, s.tok_off + s.n_tok)
+                    self._ready_spans.append(ps.span([m.mask_token[s.name]]))
+                M = g.Beff * g.N  # noqa: N806
+                hip.cast_bf16(gbuf["dy_e2d"], gbuf["dy_e2d16"], M * Dd)
+                lin = m.enc_to_dec[g.model]
+                hip.gemm(hip.GEMM_NN, M, E, Dd, gbuf["dy_e2d16"], Dd, ps.h(lin.weight), E, gbuf["dhenc"], E)
+                hip.gemm(hip.GEMM_TN, Dd, E, M, gbuf["dy_e2d16"], Dd, gbuf["henc"], E, ps.g(lin.weight), E, AT)
+                hip.colsum(gbuf["dy_e2d16"], ps.g(lin.bias), M, Dd, Dd)
+                self._grads_ready(lin)
+                if self.joint is not None:   # final LN of the joint encoder, this group's rows
+                    jt = self.joint
+                    jn = jt.t.norm
+                    hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, jt.x_last, m.joint_N, g.joint_off, jn.weight, gbuf["mean_j"],
+                                      gbuf["rstd_j"], None, jt.dxa, jt.dxa16, ps.g(jn.weight), ps.g(jn.bias),
+                                      jt.top_bias_grad(), gbuf["ln_ws"], g.Beff, g.N, E)
+            return run
+
+        self._run_parallel([side(g) for g in self.groups])
+
+    def _bwd_joint(self) -> None:
+        jt = self.joint
+        self._djoint = jt.backward(jt.dxa, jt.dxa16)
+        self._grads_ready(jt.t.norm)
+
+    def _bwd_encoder_side(self) -> None:
+        m, E, ps = self.model, self.E, self.store  # noqa: N806
+        AT = hip.OUT_F32 | hip.ATOMIC  # noqa: N806
+
+        def side(g):
+            def run():
+                gbuf, st = self.gb[g.name], self.enc[g.name]
+                nrm = st.t.norm
+                if self.joint is not None:
+                    hip.layernorm_bwd(self._djoint, m.joint_N, g.joint_off, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"],
+                                      gbuf["rstd_e"], None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias),
+                                      st.top_bias_grad(), gbuf["ln_ws"], g.Beff, g.N, E)
+                else:
+                    hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"], gbuf["rstd_e"],
+                                      None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(),
+                                      gbuf["ln_ws"], g.Beff, g.N, E)
+                dx0 = st.backward(st.dxa, st.dxa16)
+                self._grads_ready(nrm)
+                # scatter to the full group sequence (masked tokens get zero), then patch-embed backward per modality
+                gbuf["dxg"].zero_()
+                hip.scatter_rows(dx0, gbuf["vis"], gbuf["dxg"], g.Beff, g.L, g.N, E, g.N, 0)
+                for s in g.mods:
+                    b = self.mb[s.name]
+                    pe = b["pe"]
+                    T = s.Beff * s.n_tok  # noqa: N806
+                    hip.embed_finish_bwd(gbuf["dxg"], b["yconv"], b["gn_stats"], pe.norm.weight, b["dyc"],
+                                         ps.g(pe.norm.weight), ps.g(pe.norm.bias), b["gn_sums"], s.Beff, s.D, s.L, E,
+                                         s.tok_off, g.L)
+                    b["dw_conv"].zero_()
+                    hip.gemm(hip.GEMM_TN, E, s.Kpad, T, b["dyc"], E, b["cols"], s.Kpad, b["dw_conv"], s.Kpad, AT)
+                    hip.unpack_rows_add(b["dw_conv"], ps.g(pe.conv.weight), E, s.K, s.Kpad)
+                    hip.colsum(b["dyc"], ps.g(pe.conv.bias), T, E, E)
+            return run
+
+        self._run_parallel([side(g) for g in self.groups])
         for name in m.patch_embed:
             self._grads_ready(m.patch_embed[name])
 

@@ -193,10 +193,13 @@ class KernelTimer:
         self.events: dict[str, list] = {}
         self.flops: dict[str, float] = {}
         self.count: dict[str, int] = {}
+        self.shapes: dict = {}
 
-    def record(self, kind: str, flops: float):
+    def record(self, kind: str, flops: float, shape=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.events.setdefault(kind, []).append((e0, e1))
+        if shape is not None:
+            self.shapes.setdefault((kind, shape), []).append((e0, e1, flops))
         self.flops[kind] = self.flops.get(kind, 0.0) + flops
         self.count[kind] = self.count.get(kind, 0) + 1
         return e0, e1
@@ -207,6 +210,15 @@ class KernelTimer:
 
     def summary(self, steps: int) -> dict:
         return {k: round(v / steps, 3) for k, v in self.totals().items()}
+
+    def by_shape(self, steps: int) -> list:
+        torch.cuda.synchronize()
+        rows = []
+        for (kind, shape), evs in self.shapes.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+            fl = sum(f for _, _, f in evs)
+            rows.append((ms / steps, kind, shape, len(evs) // steps, fl / (ms * 1e-3) / 1e12))
+        return sorted(rows, reverse=True)
 
     def roofline(self, peak_tflops: float) -> dict:
         tot = self.totals()
@@ -227,6 +239,10 @@ def set_kernel_timer(t: KernelTimer | None) -> None:
     _timer = t
 
 
+def kernel_timer_active() -> bool:
+    return _timer is not None
+
+
 _gemm_raw = gemm
 _attn_fwd_raw, _attn_bwd_raw = attn_fwd, attn_bwd
 
@@ -234,7 +250,7 @@ _attn_fwd_raw, _attn_bwd_raw = attn_fwd, attn_bwd
 def gemm(layout, M, N, K, *a, **k):  # noqa: F811
     if _timer is None:
         return _gemm_raw(layout, M, N, K, *a, **k)
-    e0, e1 = _timer.record(_GEMM_KERNEL[layout], 2.0 * M * N * K)
+    e0, e1 = _timer.record(_GEMM_KERNEL[layout], 2.0 * M * N * K, (M, N, K))
     e0.record()
     _gemm_raw(layout, M, N, K, *a, **k)
     e1.record()
@@ -243,7 +259,7 @@ def gemm(layout, M, N, K, *a, **k):  # noqa: F811
 def attn_fwd(qkv, out, lse, B, N, H, D, scale):  # noqa: F811
     if _timer is None:
         return _attn_fwd_raw(qkv, out, lse, B, N, H, D, scale)
-    e0, e1 = _timer.record("attn_fwd", 4.0 * B * H * N * N * D)
+    e0, e1 = _timer.record("attn_fwd", 4.0 * B * H * N * N * D, (B, N, H, D))
     e0.record()
     _attn_fwd_raw(qkv, out, lse, B, N, H, D, scale)
     e1.record()
@@ -252,7 +268,7 @@ def attn_fwd(qkv, out, lse, B, N, H, D, scale):  # noqa: F811
 def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):  # noqa: F811
     if _timer is None:
         return _attn_bwd_raw(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale)
-    e0, e1 = _timer.record("attn_bwd", 10.0 * B * H * N * N * D)  # algorithmic 5 matmuls (the kernels recompute 2 more)
+    e0, e1 = _timer.record("attn_bwd", 10.0 * B * H * N * N * D, (B, N, H, D))  # algorithmic 5 matmuls (the kernels recompute 2 more)
     e0.record()
     _attn_bwd_raw(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale)
     e1.record()

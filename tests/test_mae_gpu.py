@@ -119,3 +119,25 @@ def test_forward_api_and_seeded_rng(golden_dir):
         assert np.array_equal(tok, ref_tok)
     np.testing.assert_allclose(out_batch["dem"].cpu().numpy(), gold["target/dem"], atol=1e-6)  # rescale_elev
     assert torch.equal(dbatch["dem"].cpu(), batch["dem"])  # caller's tensor is left untouched
+
+
+def test_graph_replay_and_streams_match_eager(golden_dir):
+    """Steps 2+ replay captured hipGraphs with group-parallel streams; results must match the eager single-stream run."""
+    dev, case, gold, ds, oracle, model, batch, noise, struct = _setup("c4_treesat", golden_dir)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    eng = model.engine(case["B"], dev, loss="l2_norm")
+    eng.use_graphs, eng.multi_stream = False, False
+    ref_loss = eng.forward(dbatch, noise=noise, struct=struct).item()
+    eng.zero_grad()
+    eng.backward()
+    ref_grad = eng.store.grad.clone()
+    eng.use_graphs, eng.multi_stream = True, True
+    for it in range(4):   # eager+streams, capture, replay, replay
+        loss = eng.forward(dbatch, noise=noise, struct=struct).item()
+        eng.zero_grad()
+        eng.backward()
+        torch.cuda.synchronize()
+        assert abs(loss - ref_loss) < 1e-5 * abs(ref_loss), (it, loss, ref_loss)
+        rel = ((eng.store.grad - ref_grad).norm() / ref_grad.norm()).item()
+        assert rel < 1e-4, (it, rel)
+    assert set(eng._graphs) >= {"forward", "bwd_dec", "bwd_joint", "bwd_enc"}
