@@ -1,0 +1,123 @@
+"""Host-side logic of the product (configs, geometry, RNG order, schedules) on CPU."""
+
+import itertools
+
+import pytest
+import torch
+
+import maestro_amd.conf as conf
+from maestro_amd.layers.utils import draw_struct_masks, pool_pos_table, posemb_sincos_2d
+from maestro_amd.ssl.mae import mae_large, mae_medium, mae_small, mae_tiny
+from maestro_amd.train.model import SSLModule
+from maestro_amd.train.optim import OneCycle, scaled_lr
+from oracle import layers as ol
+from oracle import mae as om
+
+ARGS = dict(interpolate="nearest", model="mae", num_levels=1, type_head="attentive", fac_abs_enc=1.0, fac_date_enc=1.0)
+
+
+def treesat():
+    return conf.DatasetsConfig(root_dir=None, name_dataset="treesatai_ts", treesatai_ts=conf.TreeSatAITSConfig(rel_dir=""))
+
+
+# mirrors the reference's tests/test_mae.py (construction for every fusion mode / option)
+@pytest.mark.parametrize("fusion_mode", ["shared", "monotemp", "mod", "group"])
+def test_mae_constructs(fusion_mode):
+    m = mae_tiny(datasets=treesat(), mask=conf.MaskConfig(), fusion_mode=fusion_mode, inter_depth=0, **ARGS)
+    want = {"shared": ["shared"], "monotemp": ["aerial", "s2", "s1_asc", "s1_des"],
+            "mod": ["aerial", "s2", "s1_asc", "s1_des"], "group": ["aerial", "s2", "s1"]}[fusion_mode]
+    assert list(m.encoder) == want and m.encoder_inter is None
+    assert "mask_token.s1_asc" in m.state_dict() and "enc_pos_encoding" not in m.state_dict()
+
+
+@pytest.mark.parametrize("factory,params_m", [(mae_medium, 176.2), (mae_large, None), (mae_small, None)])
+def test_sizes_and_state_dict_keys_match_oracle(factory, params_m):
+    ds = conf.DatasetsConfig(name_dataset="flair", flair=conf.FLAIRConfig(filter_inputs=["aerial", "s2"], filter_targets=[]))
+    m = factory(datasets=ds, mask=conf.MaskConfig(), fusion_mode="group", inter_depth=3, **ARGS)
+    size = {mae_medium: "medium", mae_large: "large", mae_small: "small"}[factory]
+    o = om.build_oracle(ds, conf.MaskConfig(), model_size=size, fusion_mode="group", inter_depth=3, **ARGS)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in o.state_dict().items()}
+    if params_m:
+        assert abs(sum(p.numel() for p in m.parameters()) / 1e6 - params_m) < 0.1
+    g = m.group_specs
+    assert (g["aerial"].L, g["aerial"].k, g["s2"].L, g["s2"].k, m.joint_N) == (1024, 768, 400, 300, 356)
+
+
+# mirrors the reference's tests/test_model.py (SSLModule construction + its two constructor errors)
+@pytest.mark.parametrize("fusion_mode,inter_depth,loss", itertools.product(["mod", "group"], [0, 3], ["l1_norm", "l1"]))
+def test_ssl_module_constructs(fusion_mode, inter_depth, loss):
+    mod = SSLModule(datasets=treesat(), mask=conf.MaskConfig(), interpolate="nearest", fusion_mode=fusion_mode,
+                    inter_depth=inter_depth, model="mae", model_size="tiny", loss=loss)
+    assert mod.model.inter_depth == inter_depth and "loss_rec_train" in mod.metrics
+    assert any(k.startswith("model.encoder.") for k in mod.state_dict())
+
+
+def test_ssl_module_errors():
+    with pytest.raises(NotImplementedError):
+        SSLModule(datasets=treesat(), mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="shared", inter_depth=3,
+                  model="mae", model_size="tiny")
+    with pytest.raises(ValueError):
+        SSLModule(datasets=treesat(), mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=0,
+                  model="mae", model_size="huge")
+    with pytest.raises(ValueError):
+        SSLModule(datasets=treesat(), mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=0,
+                  model="mae", model_size="tiny", loss="l3")
+
+
+def test_positional_tables_match_oracle():
+    assert torch.equal(posemb_sincos_2d(12, 12, 40, 8), ol.posemb_sincos_2d(12, 12, 40, 8))
+    tab = posemb_sincos_2d(96, 96, 24, 8)
+    for grid in (3, 5, 15, 96):
+        assert torch.equal(pool_pos_table(tab, grid), ol.pool_pos_encoding(tab, grid))
+
+
+@pytest.mark.parametrize("fusion_mode", ["group", "mod", "shared"])
+def test_struct_mask_draw_order_matches_oracle(fusion_mode):
+    """Same global seed -> the product's host draws equal the oracle's (which equal the reference's, see goldens)."""
+    ds = treesat()
+    kw = dict(fusion_mode=fusion_mode, inter_depth=0, **ARGS)
+    m = mae_tiny(datasets=ds, mask=conf.MaskConfig(), depth=2, **kw)
+    o = om.build_oracle(ds, conf.MaskConfig(), model_size="tiny", depth=2, **kw)
+    B = 3
+    fold = fusion_mode in ("shared", "monotemp")
+    for s in m.mod_specs.values():
+        s.Beff = B * s.Dates if fold else B
+    groups = list(m.group_specs.values())
+    for g in groups:
+        g.Beff = g.mods[0].Beff
+    torch.manual_seed(123)
+    got = draw_struct_masks(groups, m.mod_specs)
+    noise_got = {g.name: torch.rand(g.Beff, g.L) for g in groups}
+    torch.manual_seed(123)
+    want = o.draw_struct_masks({g.name: (g.Beff, g.L) for g in groups})
+    noise_want = {g.name: torch.rand(g.Beff, g.L) for g in groups}
+    for g in groups:
+        assert torch.equal(got[g.name], want[g.name][:, :, 0])
+        assert torch.equal(noise_got[g.name], noise_want[g.name])
+        assert g.k == om.OracleMAE.num_masked(o.mask_ratio[g.name], g.L)
+
+
+def test_onecycle_matches_torch_and_lr_rule():
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1.0)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=0.37, total_steps=50, pct_start=0.2, cycle_momentum=False,
+                                                div_factor=1000, final_div_factor=1e4)
+    mine = OneCycle(0.37, 50, 0.2, 1000.0, 1e4)
+    for step in range(50):
+        assert abs(opt.param_groups[0]["lr"] - mine.lr(step)) < 1e-9
+        opt.step()
+        if step < 49:
+            sched.step()
+    assert abs(scaled_lr(3e-5, 32, 1, 1, 8) - 3e-5 * (32 * 8 / 3.0) ** 0.5) < 1e-12
+
+
+def test_config_loader_cli_grammar():
+    cfg = conf.load_experiment(["datasets.name_dataset=flair", "datasets.flair.filter_inputs=[aerial,s2]",
+                                "datasets.flair.filter_targets=[]", "model.model_size=medium", "opt_pretrain.batch_size=64",
+                                "mask.mask_ratio=0.6", "datasets.flair.s2.num_dates=8"])
+    assert list(cfg["datasets"].dataset.inputs) == ["aerial", "s2"] and cfg["datasets"].dataset.s2.num_dates == 8
+    assert cfg["model"].model_size == "medium" and cfg["opt_pretrain"].batch_size == 64 and cfg["mask"].mask_ratio == 0.6
+    with pytest.raises(ValueError):
+        conf.load_experiment(["model.nope=1"])
+    with pytest.raises(ValueError):
+        conf.FLAIRConfig(ref_input="spot")
