@@ -51,14 +51,23 @@ def build_model(workload: str):
     return ds, model
 
 
-def cpu_baseline(workload: str, seconds: float) -> dict:
+def host_cores() -> int:
+    """Threads for the CPU leg: the affinity mask, capped at the 16-core share a 1-GPU box gets."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def cpu_baseline_worker(workload: str, seconds: float) -> dict:
     """The oracle (CPU restatement = kind "port") timed on this node's host cores on a bounded sample."""
     from maestro_amd.train.trainer import synthetic_batch
     from oracle import mae as om
 
     w = WORKLOADS[workload]
     ds = w["ds"]()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.set_float32_matmul_precision("highest")
     torch.manual_seed(42)
@@ -84,7 +93,26 @@ def cpu_baseline(workload: str, seconds: float) -> dict:
     med = times[len(times) // 2]
     return {"value": round(B / med, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} timed steps (after 1 warm-up) of the same {workload} workload at B={B}, fp32, "
-                      f"torch CPU threads={cores}, forward+loss+backward+AdamW"}
+                      f"torch CPU threads={cores}, forward+loss+backward+AdamW, median step {med:.2f} s"}
+
+
+def cpu_baseline(workload: str, seconds: float) -> dict:
+    """Run the CPU leg in a child process with a hard wall-clock cap so the default bench always finishes in minutes."""
+    import subprocess
+
+    cap = 6 * seconds + 60
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", workload, "--cpu-seconds", str(seconds)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(host_cores()), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=cap, env=env)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "tiles/s", "cores": host_cores(), "kind": "port",
+                "sample": f"CPU leg failed (rc={r.returncode}): {r.stderr.strip()[-200:]}"}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "tiles/s", "cores": host_cores(), "kind": "port",
+                "sample": f"CPU leg exceeded its {cap:.0f} s cap on this host"}
 
 
 def main() -> None:
@@ -97,8 +125,12 @@ def main() -> None:
     ap.add_argument("--loss", default="l2_norm")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--shapes", action="store_true", help="print per-shape kernel times to stderr (diagnostic)")
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_worker(args.config, args.cpu_seconds)), flush=True)
+        return
 
     import torch.distributed as dist
     from maestro_amd import hip
@@ -168,6 +200,12 @@ def main() -> None:
         }
         if timer is not None:
             out["roofline"] = timer.roofline(MFMA_PEAK_TFLOPS)
+            traffic_file = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+            if os.path.exists(traffic_file):  # PMC passes are separate runs (rocprofv3 --pmc); committed summary
+                kern = json.load(open(traffic_file))["kernels"].get(out["roofline"]["kernel"])
+                if kern:
+                    out["roofline"]["traffic"] = kern["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             out["roofline"]["measured_over"] = f"{args.steps} eagerly launched single-stream steps right after the timed region"
             out["kernel_times_ms_per_step"] = timer.summary(args.steps)
         if timer is not None and args.shapes:
