@@ -23,6 +23,8 @@ struct GemmParams {
     const float* bias; const float* res; const bf16_t* aux_in; bf16_t* aux_out;
     int M, N, K, lda, ldb, ldc, ldr, ldaux, flags;
     int tiles_m, tiles_n, k_per_split;
+    int fast;               // 1: buffer-load path (no K tail inside a K-minor operand, extents < 2 GiB)
+    unsigned a_bytes, b_bytes;
 };
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
@@ -55,6 +57,27 @@ __device__ __forceinline__ void load_tile(const bf16_t* __restrict__ P, int ld, 
             v[i] = z;
         }
     }
+}
+
+// ---- fast path: buffer loads.  The 128-bit resource descriptor carries the exact byte extent of the operand, so rows
+// beyond M / N (K-minor) or beyond K (K-major) read as zero in hardware; per-thread byte offsets are loop-invariant
+// 32-bit VGPRs and the K advance is ONE scalar offset -> no per-step predication, no 64-bit vector address math.
+template <bool KMAJOR>
+__device__ __forceinline__ void tile_offsets(int ld, int row0, int (&voff)[4]) {
+    const int t = threadIdx.x;
+    if constexpr (!KMAJOR) {
+        const int c = t & 7, r = t >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) voff[i] = ((row0 + r + 32 * i) * ld + c * 8) * 2;
+    } else {
+        const int c = t & 15, kk = t >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) voff[i] = ((kk + 16 * i) * ld + row0 + c * 8) * 2;
+    }
+}
+__device__ __forceinline__ void load_tile_fast(__amdgpu_buffer_rsrc_t rsrc, const int (&voff)[4], int soff, u32x4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], soff, 0);
 }
 
 // ---- registers -> swizzled LDS tile
@@ -98,8 +121,11 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* tile, int rc0, 
     }
 }
 
+// Measured alternatives that lost on MI355X (kept out of the code): a second register set / 2-step-deep prefetch (halves
+// occupancy, ~2x slower); one LDS buffer + two barriers per K step at 4 workgroups per CU (NN/TN spill under the
+// 128-VGPR cap, NT no faster); select-based branch-free predication (slower than exec-mask branches).
 template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // A0 A1 B0 B1
     const int nwg = p.tiles_m * p.tiles_n;
     // XCD-aware + grouped rasterisation: every XCD gets a contiguous run of ids, and ids walk GROUP_M m-tiles before
@@ -127,23 +153,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
         for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     u32x4 ra[4], rb[4];
-    if (nk > 0) {
-        load_tile<A_KMAJOR>(p.A, p.lda, m0, p.M, kbeg, kend, ra);
-        load_tile<B_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg, kend, rb);
-        store_tile<A_KMAJOR>(smem, ra);
-        store_tile<B_KMAJOR>(smem + 2 * TILE_BYTES, rb);
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const unsigned char* ta = smem + cur * TILE_BYTES;
-        const unsigned char* tb = smem + (2 + cur) * TILE_BYTES;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            load_tile<A_KMAJOR>(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, ra);
-            load_tile<B_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, rb);
-        }
+    auto compute = [&](const unsigned char* ta, const unsigned char* tb) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 fa[4], fb[4];
@@ -157,11 +167,60 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
                 for (int i = 0; i < 4; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
-        if (more) {
-            store_tile<A_KMAJOR>(smem + (cur ^ 1) * TILE_BYTES, ra);
-            store_tile<B_KMAJOR>(smem + (2 + (cur ^ 1)) * TILE_BYTES, rb);
-        }
+    };
+    if (p.fast) {
+        const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)p.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, (short)0, (int)p.b_bytes, 0x00020000);
+        int va[4], vb[4];
+        tile_offsets<A_KMAJOR>(p.lda, m0, va);
+        tile_offsets<B_KMAJOR>(p.ldb, n0, vb);
+        const int a_step = A_KMAJOR ? BK * p.lda * 2 : BK * 2;   // bytes per K step
+        const int b_step = B_KMAJOR ? BK * p.ldb * 2 : BK * 2;
+        int a_off = A_KMAJOR ? kbeg * p.lda * 2 : kbeg * 2;
+        int b_off = B_KMAJOR ? kbeg * p.ldb * 2 : kbeg * 2;
+        load_tile_fast(ra_src, va, a_off, ra);
+        load_tile_fast(rb_src, vb, b_off, rb);
+        store_tile<A_KMAJOR>(smem, ra);
+        store_tile<B_KMAJOR>(smem + 2 * TILE_BYTES, rb);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nk;
+            if (more) {
+                a_off += a_step; b_off += b_step;
+                load_tile_fast(ra_src, va, a_off, ra);
+                load_tile_fast(rb_src, vb, b_off, rb);
+            }
+            compute(smem + cur * TILE_BYTES, smem + (2 + cur) * TILE_BYTES);
+            if (more) {
+                store_tile<A_KMAJOR>(smem + (cur ^ 1) * TILE_BYTES, ra);
+                store_tile<B_KMAJOR>(smem + (2 + (cur ^ 1)) * TILE_BYTES, rb);
+            }
+            __syncthreads();
+        }
+    } else {
+        // general path (K tail inside a K-minor operand; tiny GEMMs only): predicated loads, one LDS buffer, two barriers per step
+        unsigned char* ta = smem;
+        unsigned char* tb = smem + TILE_BYTES;
+        load_tile<A_KMAJOR>(p.A, p.lda, m0, p.M, kbeg, kend, ra);
+        load_tile<B_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg, kend, rb);
+        store_tile<A_KMAJOR>(ta, ra);
+        store_tile<B_KMAJOR>(tb, rb);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+            if (more) {
+                load_tile<A_KMAJOR>(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, ra);
+                load_tile<B_KMAJOR>(p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, rb);
+            }
+            compute(ta, tb);
+            __syncthreads();
+            if (more) {
+                store_tile<A_KMAJOR>(ta, ra);
+                store_tile<B_KMAJOR>(tb, rb);
+            }
+            __syncthreads();
+        }
     }
 
     const int g = l >> 4, lm = l & 15;
@@ -296,6 +355,17 @@ extern "C" int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int 
     const int ksteps_per = ceil_div(ceil_div(K, BK), splits);
     p.k_per_split = ksteps_per * BK;
     splits = ceil_div(K, p.k_per_split);
+    // Buffer-load fast path: K-minor operands must have no K tail inside a K step (it would wrap into the next row
+    // instead of reading zero); K-major operands zero-fill beyond K by the descriptor extent.  Split ranges are whole
+    // K steps, so the only tail is the global one.
+    const bool a_kmajor = layout == 2, b_kmajor = layout != 0;
+    const long a_ext = a_kmajor ? ((long)(K - 1) * lda + M) * 2 : ((long)(M - 1) * lda + K) * 2;
+    const long b_ext = b_kmajor ? ((long)(K - 1) * ldb + N) * 2 : ((long)(N - 1) * ldb + K) * 2;
+    const long a_reach = a_kmajor ? (long)(ceil_div(K, BK) * BK) * lda * 2 : (long)(p.tiles_m * BM) * lda * 2;
+    const long b_reach = b_kmajor ? (long)(ceil_div(K, BK) * BK) * ldb * 2 : (long)(p.tiles_n * BN) * ldb * 2;
+    const bool tail_ok = (a_kmajor || K % BK == 0) && (b_kmajor || K % BK == 0);
+    p.fast = tail_ok && a_reach + 4096 < (1L << 31) && b_reach + 4096 < (1L << 31);
+    p.a_bytes = (unsigned)a_ext; p.b_bytes = (unsigned)b_ext;
     dim3 grid(p.tiles_m * p.tiles_n, splits), block(NT);
     hipStream_t s = (hipStream_t)stream;
     switch (layout) {
