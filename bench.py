@@ -126,6 +126,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--shapes", action="store_true", help="print per-shape kernel times to stderr (diagnostic)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -142,11 +143,18 @@ def main() -> None:
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks need {world} GPUs (found {ndev}); one process per GPU")
+    local = local % max(ndev, 1)   # only differs from LOCAL_RANK in single-GPU gloo rehearsals
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     torch.manual_seed(42 + rank)
     ds, model = build_model(args.config)
