@@ -168,6 +168,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmParams p) {
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
     };
+    auto compute_half = [&](const unsigned char* ta, const unsigned char* tb, int s) {
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KMAJOR>(ta, wm + 16 * i, s);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR>(tb, wn + 16 * j, s);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+    };
     if (p.fast) {
         const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)p.a_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, (short)0, (int)p.b_bytes, 0x00020000);
@@ -178,24 +190,34 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmParams p) {
         const int b_step = B_KMAJOR ? BK * p.ldb * 2 : BK * 2;
         int a_off = A_KMAJOR ? kbeg * p.lda * 2 : kbeg * 2;
         int b_off = B_KMAJOR ? kbeg * p.ldb * 2 : kbeg * 2;
+        // Software pipeline (one register set, two LDS buffers): tile kt+1 is written to LDS in the MIDDLE of step kt
+        // (between the two 16-MFMA halves) and the loads of tile kt+2 are re-issued right behind it, so every load has
+        // a full step of latency cover and the barrier at the end of the step is not preceded by a vmcnt wait.
         load_tile_fast(ra_src, va, a_off, ra);
         load_tile_fast(rb_src, vb, b_off, rb);
         store_tile<A_KMAJOR>(smem, ra);
         store_tile<B_KMAJOR>(smem + 2 * TILE_BYTES, rb);
+        if (nk > 1) {
+            a_off += a_step; b_off += b_step;
+            load_tile_fast(ra_src, va, a_off, ra);
+            load_tile_fast(rb_src, vb, b_off, rb);
+        }
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            const bool more = kt + 1 < nk;
-            if (more) {
-                a_off += a_step; b_off += b_step;
-                load_tile_fast(ra_src, va, a_off, ra);
-                load_tile_fast(rb_src, vb, b_off, rb);
-            }
-            compute(smem + cur * TILE_BYTES, smem + (2 + cur) * TILE_BYTES);
-            if (more) {
+            const unsigned char* ta = smem + cur * TILE_BYTES;
+            const unsigned char* tb = smem + (2 + cur) * TILE_BYTES;
+            compute_half(ta, tb, 0);
+            if (kt + 1 < nk) {
                 store_tile<A_KMAJOR>(smem + (cur ^ 1) * TILE_BYTES, ra);
                 store_tile<B_KMAJOR>(smem + (2 + (cur ^ 1)) * TILE_BYTES, rb);
+                if (kt + 2 < nk) {
+                    a_off += a_step; b_off += b_step;
+                    load_tile_fast(ra_src, va, a_off, ra);
+                    load_tile_fast(rb_src, vb, b_off, rb);
+                }
             }
+            compute_half(ta, tb, 1);
             __syncthreads();
         }
     } else {

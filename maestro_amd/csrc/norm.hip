@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // Backward. Each wave walks ROWS_PER_WAVE rows keeping per-column partials of dgamma, dbeta and colsum(dx) in
 // registers; the block reduces them through LDS and writes ONE partial row [3*dim] to the workspace (plain stores);
 // ln_bwd_reduce_kernel then sums the partial rows (few atomics per column, no same-address storm).
-constexpr int ROWS_PER_WAVE = 8;
+constexpr int ROWS_PER_WAVE = 4;  // 16 rows per block: >= 2 blocks per CU at M = 8192 (8 was bandwidth-starved: 256 blocks)
 
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, RowMap dym, int dy_is_f32,

@@ -324,8 +324,19 @@ class MAEEngine:
         self._ready_spans = []
         if seen == key:  # second time with the same addresses: capture (the first eager run warmed everything up)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            try:
+                # thread_local: other threads (e.g. the RCCL watchdog polling events) must not invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    fn()
+            except Exception as exc:  # noqa: BLE001 -- capture is an optimisation: fall back to eager launches
+                import warnings
+                warnings.warn(f"hipGraph capture of segment {name!r} failed ({exc}); continuing with eager launches")
+                self.use_graphs = False
+                torch.cuda.synchronize()
+                self._ready_spans = []
                 fn()
+                self._flush_ready(self._ready_spans)
+                return
             self._graphs[name] = {"key": key, "graph": graph, "spans": list(self._ready_spans)}
             graph.replay()
         else:
