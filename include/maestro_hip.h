@@ -104,6 +104,9 @@ int mh_embed_finish_bwd(const float* dxg, const float* y, const float* stats, co
  * [B, 1, 3] -> out f32 [B, rows, 8] rows [row_off, row_off + D): fac * [diff x4, sin/cos doy, sin/cos hour]. */
 int mh_date_features(const int16_t* dates, const int16_t* ref_date, float* out, int B, int D, int rows, int row_off,
                      float fac, void* stream);
+/* Input staging: resize rasters to image_size (maestro/ssl/mim.py:427-432, F.interpolate with align_corners=False).
+ * in f32 [planes, Hin, Win] -> out f32 [planes, Hout, Wout]; mode 0 nearest, 1 bilinear (PyTorch index maps). */
+int mh_resize(const float* in, float* out, long planes, int Hin, int Win, int Hout, int Wout, int mode, void* stream);
 /* Elevation rescale copy (maestro/ssl/mim.py:433-436): out[:, c>=1] = 30 * (img[:, 0] - img[:, c]); out != img. */
 int mh_rescale_elev(const float* img, float* out, int BD, int C, int S, void* stream);
 /* Patch layout [BD*g*g, P*P*C] -> image [BD, C, S, S] ('(p1 p2 c) h w -> c (h p1) (w p2)', embed.py:153-160). */

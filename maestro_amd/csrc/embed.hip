@@ -246,7 +246,39 @@ __global__ __launch_bounds__(256) void rescale_elev_kernel(const float* __restri
     out[i] = c == 0 ? v : 30.f * (img[(bd * C) * plane + px] - v);
 }
 
+// ---- raster resize to image_size (maestro/ssl/mim.py:427-432 -> F.interpolate, align_corners=False): PyTorch's index maps
+// mode 0 nearest: src = min(floor(dst * in/out), in-1); mode 1 bilinear: src = max((dst+0.5)*in/out - 0.5, 0)
+__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ in, float* __restrict__ out, int Hin, int Win,
+                                                     int Hout, int Wout, int mode, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = i % Wout; const long r = i / Wout; const int y = r % Hout; const long plane = r / Hout;
+    const float* src = in + plane * (long)Hin * Win;
+    const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
+    if (mode == 0) {
+        const int yy = min((int)floorf(y * sy), Hin - 1), xx = min((int)floorf(x * sx), Win - 1);
+        out[i] = src[(long)yy * Win + xx];
+        return;
+    }
+    const float fy = fmaxf(sy * (y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sx * (x + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    out[i] = hy * (hx * src[(long)y0 * Win + x0] + lx * src[(long)y0 * Win + x1]) +
+             ly * (hx * src[(long)y1 * Win + x0] + lx * src[(long)y1 * Win + x1]);
+}
+
 }  // namespace
+
+extern "C" int mh_resize(const float* in, float* out, long planes, int Hin, int Win, int Hout, int Wout, int mode, void* stream) {
+    MH_CHECK_ARG(in && out && in != out && planes > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "mh_resize: bad arguments");
+    MH_CHECK_ARG(mode == 0 || mode == 1, "mh_resize: mode %d (0 nearest, 1 bilinear; bicubic is not built)", mode);
+    const long total = planes * Hout * Wout;
+    hipLaunchKernelGGL(resize_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, Hin, Win, Hout, Wout,
+                       mode, total);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int mh_date_features(const int16_t* dates, const int16_t* ref_date, float* out, int B, int D, int rows, int row_off,
                                 float fac, void* stream) {

@@ -364,15 +364,25 @@ class MAEEngine:
             gbuf["struct_h"].copy_(struct[g.name].reshape(g.Beff, g.L).to(U8))
             gbuf["noise"].copy_(gbuf["noise_h"], non_blocking=True)
             gbuf["struct"].copy_(gbuf["struct_h"], non_blocking=True)
+        batch = dict(batch)
         for s in self.mods.values():
             img = batch[s.name]
-            if tuple(img.shape[-2:]) != (s.S, s.S):
-                raise NotImplementedError("input rasters must already be at image_size (resize: SURVEY §8(f) next)")
             if img.dtype != F32 or not img.is_contiguous() or not img.is_cuda:
                 raise ValueError(f"batch[{s.name!r}] must be a contiguous float32 GPU tensor")
+            if tuple(img.shape[-2:]) != (s.S, s.S) or self.model.interpolate != "nearest":
+                # input staging (mim.py:427-432): resize to image_size on the GPU into an engine-owned buffer
+                mode = {"nearest": 0, "bilinear": 1}.get(self.model.interpolate)
+                if mode is None:
+                    raise NotImplementedError(f"interpolate={self.model.interpolate!r} is not built (nearest, bilinear)")
+                buf = self.mb[s.name].get("resized")
+                if buf is None:
+                    buf = self.mb[s.name]["resized"] = torch.empty(self.B, s.Dates, s.C, s.S, s.S, dtype=F32, device=self.device)
+                hip.resize(img, buf, self.B * s.Dates * s.C, img.shape[-2], img.shape[-1], s.S, s.S, mode)
+                batch[s.name] = buf
             d = batch[f"{s.name}_dates"]
             if d.dtype != torch.int16 or not d.is_contiguous():
                 raise ValueError(f"batch['{s.name}_dates'] must be a contiguous int16 tensor [B, D, 3]")
+        self._staged = batch
         key = self._cur_key = tuple(batch[k].data_ptr() for k in sorted(batch) if isinstance(batch[k], torch.Tensor))
         self._segment("forward", key, lambda: self._forward_launches(batch))
         return self.loss_acc
@@ -580,9 +590,10 @@ class MAEEngine:
     def returned_batch(self, batch: dict) -> dict:
         """The reference returns the (in place) resized / elevation-rescaled batch (mim.py:425-437)."""
         out = dict(batch)
+        out.update({s.name: self._staged[s.name] for s in self.mods.values()})  # resized rasters (mim.py:427-432)
         for s in self.mods.values():
             if s.rescale_elev:
-                img = batch[s.name]
+                img = out[s.name]
                 res = torch.empty_like(img)
                 hip.rescale_elev(img, res, img.shape[0] * img.shape[1], s.C, s.S)
                 out[s.name] = res

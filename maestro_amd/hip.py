@@ -122,6 +122,10 @@ def date_features(dates, ref_date, out, B, D, rows, row_off, fac):
     call("mh_date_features", dates, ref_date, out, _I(B), _I(D), _I(rows), _I(row_off), _F(fac))
 
 
+def resize(src, dst, planes, Hin, Win, Hout, Wout, mode):
+    call("mh_resize", src, dst, _L(planes), _I(Hin), _I(Win), _I(Hout), _I(Wout), _I(mode))
+
+
 def rescale_elev(img, out, BD, C, S):
     call("mh_rescale_elev", img, out, _I(BD), _I(C), _I(S))
 

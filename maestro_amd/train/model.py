@@ -86,6 +86,7 @@ class SSLModule(_Base):
         if loss not in ("l1", "l2", "l1_norm", "l2_norm"):
             raise ValueError(f"Invalid loss {loss}.")
         self.loss_name, self.norm_pix_loss = loss, loss.endswith("_norm")
+        self._model_size, self._type_head, self._mask = model_size, type_head, mask
         if model != "mae":
             raise ValueError(f"Invalid model name {model}. Not implemented")
         model_map = {"tiny": mae_tiny, "small": mae_small, "medium": mae_medium, "large": mae_large}
@@ -110,6 +111,43 @@ class SSLModule(_Base):
                 self.trainer = SimpleNamespace(ssl_phase="pretrain")
             except Exception:  # noqa: BLE001  (Lightning exposes trainer as a property that raises when detached)
                 pass
+
+    # ------------------------------------------------------------------ checkpoints (Lightning .ckpt layout)
+    def checkpoint(self, **extra) -> dict:
+        """Lightning-style checkpoint dict: ``state_dict`` with the reference's keys + ``hyper_parameters``."""
+        sd = {k: v.detach().cpu().clone() for k, v in self.state_dict().items() if k != "_anchor"}
+        hp = dict(interpolate=self.model.interpolate, fusion_mode=self.model.fusion_mode, inter_depth=self.model.inter_depth,
+                  model="mae", model_size=self._model_size, type_head=self._type_head, loss=self.loss_name,
+                  use_date_enc=self.model.fac_date_enc != 0.0, use_ema=self.ema_model is not None, mask=vars(self._mask))
+        return {"state_dict": sd, "hyper_parameters": hp, "pytorch-lightning_version": "maestro_amd", **extra}
+
+    def save_checkpoint(self, path, **extra) -> None:
+        torch.save(self.checkpoint(**extra), path)
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict: bool = False, datasets=None, **overrides):
+        """Counterpart of ``LightningModule.load_from_checkpoint`` as the reference calls it
+        (``maestro/run_experiment.py:66-73``: ``strict=False, datasets=datasets``).  Reads reference checkpoints
+        (e.g. the HF ``MAESTRO_*_base`` weights): same keys; ``heads.*`` / ``ema_model.*`` entries that this build does not
+        instantiate are skipped when ``strict=False``."""
+        from maestro_amd.conf import MaskConfig
+
+        ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+        hp = dict(ckpt.get("hyper_parameters", {}))
+        hp.update(overrides)
+        if datasets is None:
+            raise ValueError("datasets must be given (it is excluded from the saved hyper-parameters, model.py:118)")
+        mask = hp.pop("mask", None)
+        mask = MaskConfig(**mask) if isinstance(mask, dict) else (mask if mask is not None else MaskConfig())
+        hp = {k: v for k, v in hp.items() if k in ("interpolate", "fusion_mode", "inter_depth", "model", "model_size",
+                                                   "type_head", "loss", "use_date_enc", "use_ema")}
+        module = cls(datasets=datasets, mask=mask, **hp)
+        missing, unexpected = module.load_state_dict(ckpt["state_dict"], strict=False)
+        missing = [k for k in missing if k != "_anchor"]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"checkpoint mismatch: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+        module.loaded_missing, module.loaded_unexpected = missing, list(unexpected)
+        return module
 
     # ------------------------------------------------------------------ optimisers (reference rule)
     def configure_optimizers(self) -> dict:

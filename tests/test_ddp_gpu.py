@@ -65,7 +65,16 @@ def test_two_ranks_stay_in_sync():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [out.get(timeout=300) for _ in procs]
+    res = []
+    for _ in procs:   # fail fast if a rank dies instead of waiting on the queue
+        for _ in range(240):
+            try:
+                res.append(out.get(timeout=1))
+                break
+            except Exception:  # noqa: BLE001
+                assert all(p.exitcode in (None, 0) for p in procs), "a rank crashed"
+        else:
+            raise AssertionError("ranks did not report within 240 s")
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -121,3 +121,23 @@ def test_config_loader_cli_grammar():
         conf.load_experiment(["model.nope=1"])
     with pytest.raises(ValueError):
         conf.FLAIRConfig(ref_input="spot")
+
+
+def test_checkpoint_round_trip_and_reference_style_keys(tmp_path):
+    mod = SSLModule(datasets=treesat(), mask=conf.MaskConfig(mask_ratio=0.6), interpolate="nearest", fusion_mode="group",
+                    inter_depth=3, model="mae", model_size="tiny", loss="l1_norm")
+    path = tmp_path / "pretrain-epoch=0.ckpt"
+    ckpt = mod.checkpoint()
+    # a reference checkpoint additionally carries heads / ema weights this build does not instantiate
+    ckpt["state_dict"]["model.heads.treesat_mlc_thresh.linear.weight"] = torch.zeros(15, 192)
+    ckpt["state_dict"]["ema_model.mask_token.aerial"] = torch.zeros(1, 1, 1, 1, 512)
+    torch.save(ckpt, path)
+    assert all(k.startswith("model.") for k in mod.checkpoint()["state_dict"])
+    new = SSLModule.load_from_checkpoint(path, map_location="cpu", strict=False, datasets=treesat())
+    assert new.loss_name == "l1_norm" and new.model.mask_ratio["aerial"] == 0.6 and new.model.inter_depth == 3
+    assert not new.loaded_missing and sorted(new.loaded_unexpected) == [
+        "ema_model.mask_token.aerial", "model.heads.treesat_mlc_thresh.linear.weight"]
+    for (k, a), (_, b) in zip(mod.model.state_dict().items(), new.model.state_dict().items()):
+        assert torch.equal(a, b), k
+    with pytest.raises(RuntimeError):
+        SSLModule.load_from_checkpoint(path, strict=True, datasets=treesat())

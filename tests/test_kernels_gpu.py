@@ -187,6 +187,20 @@ def test_date_features_and_rescale(dev):
     assert torch.equal(res.cpu(), ref_img)
 
 
+@pytest.mark.parametrize("mode,name", [(0, "nearest"), (1, "bilinear")])
+@pytest.mark.parametrize("hin,hout", [(32, 64), (64, 64), (100, 60), (6, 10), (37, 128)])
+def test_resize_matches_torch_interpolate(dev, mode, name, hin, hout):
+    from maestro_amd import hip
+    x = torch.rand(3, 2, hin, hin, generator=torch.Generator().manual_seed(hin))
+    out = torch.zeros(3, 2, hout, hout, device=dev)
+    hip.resize(x.to(dev), out, 6, hin, hin, hout, hout, mode)
+    want = F.interpolate(x, size=(hout, hout), mode=name)
+    if mode == 0:
+        assert torch.equal(out.cpu(), want)
+    else:
+        assert (out.cpu() - want).abs().max() < 2e-6
+
+
 def test_depatchify(dev):
     from maestro_amd import hip
     from oracle import mae as om

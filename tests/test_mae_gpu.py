@@ -141,3 +141,20 @@ def test_graph_replay_and_streams_match_eager(golden_dir):
         rel = ((eng.store.grad - ref_grad).norm() / ref_grad.norm()).item()
         assert rel < 1e-4, (it, rel)
     assert set(eng._graphs) >= {"forward", "bwd_dec", "bwd_joint", "bwd_enc"}
+
+
+@pytest.mark.parametrize("interpolate", ["nearest", "bilinear"])
+def test_input_resize_staging_matches_oracle(golden_dir, interpolate):
+    """Rasters arriving at another resolution are resized on the GPU (mim.py:427-432) exactly like the oracle/reference."""
+    dev, case, gold, ds, oracle, model, batch, noise, struct = _setup("c3_aerial_s2", golden_dir)
+    model.interpolate = oracle.interpolate = interpolate
+    small = dict(batch)
+    small["aerial"] = torch.nn.functional.avg_pool2d(batch["aerial"].flatten(0, 1), 2).unflatten(0, batch["aerial"].shape[:2]).contiguous()
+    eng = model.engine(case["B"], dev, loss="l2_norm")
+    loss = eng.forward({k: v.to(dev) for k, v in small.items()}, noise=noise, struct=struct)
+    ob = {k: v.clone() for k, v in small.items()}
+    ob, orec, omsk, _ = oracle(ob, "pretrain", noise=noise, struct_masks={g: s[:, :, None] for g, s in struct.items()})
+    oloss = om.compute_loss_rec(ob, orec, omsk, oracle.out_grid_size, om.norm_bands_of(ds.dataset), "l2_norm")
+    assert abs(loss.item() - oloss.item()) < 2e-2 * abs(oloss.item())
+    returned = eng.returned_batch({k: v.to(dev) for k, v in small.items()})
+    assert (returned["aerial"].cpu() - ob["aerial"]).abs().max() < 2e-6 and returned["aerial"].shape[-1] == 64
