@@ -155,26 +155,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         bf16x8 pf[2][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
+            // running max on the RAW scores (scale > 0 commutes with max); scale and max folded into one FMA per element
+            if (tail) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kv0 + 16 * kt + 4 * g + r >= N) s[qt][kt][r] = -INFINITY;
+            }
             float mx = m[qt];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = s[qt][kt][r] * c;
-                    if (tail && kv0 + 16 * kt + 4 * g + r >= N) x = -INFINITY;
-                    s[qt][kt][r] = x;
-                    mx = fmaxf(mx, x);
-                }
+                mx = fmaxf(fmaxf(mx, fmaxf(s[qt][kt][0], s[qt][kt][1])), fmaxf(s[qt][kt][2], s[qt][kt][3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float alpha = exp2_fast(m[qt] - mx);  // first tile: exp2(-inf) = 0
+            const float alpha = exp2_fast((m[qt] - mx) * c);  // first tile: exp2(-inf) = 0
             m[qt] = mx;
+            const float mc = mx * c;
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = exp2_fast(s[qt][kt][r] - mx);
+                    const float pv = exp2_fast(fmaf(s[qt][kt][r], c, -mc));
                     s[qt][kt][r] = pv;
                     ps += pv;
                 }
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             *reinterpret_cast<u32x2*>(orow + 16 * dt + 4 * g) = pk;
         }
-        if (g == 0) lse[((size_t)b * H + h) * N + q] = (m[qt] + log2f(lt)) * 0.6931471805599453f;
+        if (g == 0) lse[((size_t)b * H + h) * N + q] = m[qt] * scale + logf(lt);  // m is a raw-score max
     }
 }
 
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                 for (int r = 0; r < 4; ++r) {
                     float pv = exp2_fast(s[qt][kt][r] * c - lse2[qt]);
                     if (tail && kv0 + 16 * kt + 4 * g + r >= N) pv = 0.f;
-                    s[qt][kt][r] = pv * (dp[qt][kt][r] - dlt[qt]) * scale;  // dS (w.r.t. raw q.k)
+                    s[qt][kt][r] = pv * (dp[qt][kt][r] - dlt[qt]);  // dS / scale; the factor is applied to dQ once at the end
                 }
             dsf[qt][0] = pack_acc(s[qt][0], s[qt][1]);
             dsf[qt][1] = pack_acc(s[qt][2], s[qt][3]);
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         bf16_t* drow = dqkv + ((size_t)b * N + q) * rs + (size_t)h * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const f32x4 v = dq[qt][dt];
+            const f32x4 v = dq[qt][dt] * scale;
             u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             *reinterpret_cast<u32x2*>(drow + 16 * dt + 4 * g) = pk;
         }
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                 for (int r = 0; r < 4; ++r) {
                     const float pv = exp2_fast(s[qt][kt][r] * c - l4[r]);  // query >= N: lse2 = +inf -> 0
                     s[qt][kt][r] = pv;
-                    dp[qt][kt][r] = pv * (dp[qt][kt][r] - d4[r]) * scale;
+                    dp[qt][kt][r] = pv * (dp[qt][kt][r] - d4[r]);  // dS / scale (applied to dK at the end)
                 }
         }
 #pragma unroll
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         bf16_t* vrow = krow + (size_t)H * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            u32x2 pk = {pack_bf2(dk[kt][dt][0], dk[kt][dt][1]), pack_bf2(dk[kt][dt][2], dk[kt][dt][3])};
+            u32x2 pk = {pack_bf2(dk[kt][dt][0] * scale, dk[kt][dt][1] * scale), pack_bf2(dk[kt][dt][2] * scale, dk[kt][dt][3] * scale)};
             u32x2 pv = {pack_bf2(dv[kt][dt][0], dv[kt][dt][1]), pack_bf2(dv[kt][dt][2], dv[kt][dt][3])};
             *reinterpret_cast<u32x2*>(krow + 16 * dt + 4 * g) = pk;
             *reinterpret_cast<u32x2*>(vrow + 16 * dt + 4 * g) = pv;
