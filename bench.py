@@ -126,6 +126,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--single-stream", action="store_true", help="profiling aid: no group-parallel streams (clean per-kernel times)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--shapes", action="store_true", help="print per-shape kernel times to stderr (diagnostic)")
     args = ap.parse_args()
@@ -160,6 +161,8 @@ def main() -> None:
     ds, model = build_model(args.config)
     loop = PretrainLoop(model, args.batch, dev, loss=args.loss, total_steps=args.steps + args.warmup, world_size=world)
     batch = synthetic_batch(ds.dataset, args.batch, dev, seed=rank)
+    if args.single_stream:
+        loop.engine.multi_stream = False
 
     def sync():
         if world > 1:

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void unmask_kernel(const float* __restrict__ y
 }
 
 // dmask_token[:] (ONE row = the gradient of modality `slot`'s mask token) += sum over its masked tokens; each block reduces a strip of token rows in registers first.
-constexpr int UM_ROWS = 16;
+constexpr int UM_ROWS = 128;  // rows per block: keeps the same-address atomics per column at B*L/128 instead of B*L/16
 __global__ __launch_bounds__(256) void unmask_bwd_token_kernel(const float* __restrict__ dxdec, const uint8_t* __restrict__ mask,
                                                                const int* __restrict__ tok_slot, float* __restrict__ dmask_token,
                                                                int B, int L, int Dd, int slot, int t_lo, int t_hi) {
