@@ -106,6 +106,7 @@ class Stack:
         self.dh, self.dh2 = e(M, mlp, dt=BF16), e(M, dim, dt=BF16)
         self.do, self.dqkv, self.delta = e(M, self.inner, dt=BF16), e(M, 3 * self.inner, dt=BF16), e(Bn * self.H * N)
         self.ln_ws = e(max(1, hip.layernorm_bwd_workspace(M, dim)))  # private: stacks of different groups run concurrently
+        self.wstream = torch.cuda.Stream(device=dev)                 # side stream for the weight-gradient GEMMs
 
     @property
     def x0(self):
@@ -138,39 +139,87 @@ class Stack:
                      hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=fc2.bias, res=x_mid, ldr=dim)
 
     def backward(self, dx_out: torch.Tensor, dx_out16: torch.Tensor):
-        """``dx_out`` (f32) / ``dx_out16`` (bf16 copy): gradient w.r.t. ``x_last``.  Returns grad w.r.t. ``x0`` (f32)."""
+        """``dx_out`` (f32) / ``dx_out16`` (bf16 copy): gradient w.r.t. ``x_last``.  Returns grad w.r.t. ``x0`` (f32).
+
+        The four weight-gradient GEMMs of a layer (+ the fc1 bias column sum) do not feed the dgrad chain, so they are
+        issued on this stack's side stream and overlap the chain's non-MFMA kernels (attention backward, LayerNorm
+        backward).  Scratch buffers are shared by all layers, hence the explicit ordering:
+          side waits  : e0 (layer input dY ready), e1 (dh), e2 (d x_mid), e3 (dqkv)          -- producers on the main stream
+          main joins the side stream once per layer, before LN1-bwd (which rewrites the dY buffer; the next layer then
+          rewrites dh / d x_mid / dqkv).  (A finer scheme with cross-layer event waits crashed hipStreamEndCapture.)
+        """
         eng, ps, M = self.eng, self.eng.store, self.M  # noqa: N806
         dim, mlp, inner = self.dim, self.mlp, self.inner
         AT = hip.OUT_F32 | hip.ATOMIC  # noqa: N806
+        overlap = eng.multi_stream and eng.overlap_wgrad and self.depth > 0
+        main = torch.cuda.current_stream()
+        ws = self.wstream
+
+        def mark():  # event recorded on the main stream at this point
+            ev = torch.cuda.Event()
+            eng._events.append(ev)   # must outlive an ongoing hipGraph capture (destroying it mid-capture crashes HIP)
+            ev.record(main)
+            return ev
+
+        def side(after, fn):  # run fn on the side stream once `after` (main-stream event) has happened
+            if not overlap:
+                fn()
+                return None
+            ws.wait_event(after)
+            with torch.cuda.stream(ws):
+                fn()
+                ev = torch.cuda.Event()
+                eng._events.append(ev)
+                ev.record(ws)
+            return ev
+
+        def wait(ev):
+            if ev is not None:
+                main.wait_event(ev)
+
+        prev_fc1 = prev_proj = prev_qkv = None
         cur, cur16 = dx_out, dx_out16
         for l in reversed(range(self.depth)):
             attn, ff = self.t.layers[l]
             s, x_in, x_mid = self.saved[l], self.xs[2 * l], self.xs[2 * l + 1]
             ln2, fc1, fc2 = ff.net[0], ff.net[1], ff.net[4]
+            proj = attn.to_out[0]
             mid, mid16 = (self.dxa, self.dxa16) if cur is not self.dxa else (self.dxb, self.dxb16)
+            nxt, nxt16 = (self.dxa, self.dxa16) if mid is not self.dxa else (self.dxb, self.dxb16)
             # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
+            e0 = mark() if overlap else None
             hip.gemm(hip.GEMM_NN, M, mlp, dim, cur16, dim, ps.h(fc2.weight), mlp, self.dh, mlp, hip.DGELU,
                      aux_in=s["hpre"], ldaux=mlp)
-            hip.gemm(hip.GEMM_TN, dim, mlp, M, cur16, dim, s["act"], mlp, ps.g(fc2.weight), mlp, AT)
+            e1 = mark() if overlap else None
+            ev_fc2 = side(e0, lambda: hip.gemm(hip.GEMM_TN, dim, mlp, M, cur16, dim, s["act"], mlp, ps.g(fc2.weight), mlp, AT))
+
+            def fc1_grads():
+                hip.gemm(hip.GEMM_TN, mlp, dim, M, self.dh, mlp, s["h2"], dim, ps.g(fc1.weight), dim, AT)
+                hip.colsum(self.dh, ps.g(fc1.bias), M, mlp, mlp)
+            prev_fc1 = side(e1, fc1_grads)
             hip.gemm(hip.GEMM_NN, M, dim, mlp, self.dh, mlp, ps.h(fc1.weight), dim, self.dh2, dim)
-            hip.gemm(hip.GEMM_TN, mlp, dim, M, self.dh, mlp, s["h2"], dim, ps.g(fc1.weight), dim, AT)
-            hip.colsum(self.dh, ps.g(fc1.bias), M, mlp, mlp)
-            proj = attn.to_out[0]
             hip.layernorm_bwd(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16,
                               ps.g(ln2.weight), ps.g(ln2.bias), ps.g(proj.bias), self.ln_ws, 1, M, dim)
             # ---- attention: x_mid = x_in + proj(attn(qkv(LN1(x_in))))
-            nxt, nxt16 = (self.dxa, self.dxa16) if mid is not self.dxa else (self.dxb, self.dxb16)
+            e2 = mark() if overlap else None
             hip.gemm(hip.GEMM_NN, M, inner, dim, mid16, dim, ps.h(proj.weight), inner, self.do, inner)
-            hip.gemm(hip.GEMM_TN, dim, inner, M, mid16, dim, s["o"], inner, ps.g(proj.weight), inner, AT)
+            prev_proj = side(e2, lambda: hip.gemm(hip.GEMM_TN, dim, inner, M, mid16, dim, s["o"], inner, ps.g(proj.weight),
+                                                  inner, AT))
             hip.attn_bwd(s["qkv"], s["o"], self.do, s["lse"], self.delta, self.dqkv, self.Bn, self.N, self.H, self.Dh,
                          attn.scale)
+            e3 = mark() if overlap else None
+            prev_qkv = side(e3, lambda: hip.gemm(hip.GEMM_TN, 3 * inner, dim, M, self.dqkv, 3 * inner, s["h1"], dim,
+                                                 ps.g(attn.to_qkv.weight), dim, AT))
             hip.gemm(hip.GEMM_NN, M, dim, 3 * inner, self.dqkv, 3 * inner, ps.h(attn.to_qkv.weight), dim, self.dh2, dim)
-            hip.gemm(hip.GEMM_TN, 3 * inner, dim, M, self.dqkv, 3 * inner, s["h1"], dim, ps.g(attn.to_qkv.weight), dim, AT)
             prev_fc2_bias = ps.g(self.t.layers[l - 1][1].net[4].bias) if l > 0 else None  # = colsum(dx_out of layer l-1)
+            if overlap:
+                main.wait_stream(ws)   # join per layer: LN1-bwd rewrites dY (bf16) and the next layer rewrites dh / d x_mid / dqkv
             hip.layernorm_bwd(self.dh2, M, 0, x_in, M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid, nxt, nxt16,
                               ps.g(attn.norm.weight), ps.g(attn.norm.bias), prev_fc2_bias, self.ln_ws, 1, M, dim)
             cur, cur16 = nxt, nxt16
             eng._grads_ready(self.t.layers[l])
+        if overlap:
+            main.wait_stream(ws)   # join: all weight gradients of this stack are complete past this point
         return cur
 
 
@@ -193,7 +242,18 @@ class MAEEngine:
         self.grad_hook = None  # callable(lo, hi) invoked when grad[lo:hi] is final (DDP bucket launch)
         self.use_graphs = True      # capture launch segments into hipGraphs once input addresses repeat
         self.multi_stream = True    # independent groups on parallel HIP streams
+        self.group_streams = True   # (only with multi_stream) groups on parallel streams
+        # Weight-gradient GEMMs on a side stream per transformer stack: measured 31.1 ms/step alone vs 25.7 ms/step for
+        # group streams alone (C3), and nesting both forks inside one hipGraph capture crashes hipStreamEndCapture
+        # (ROCm 7.2) -> off by default; MAESTRO_WGRAD_OVERLAP=1 MAESTRO_GROUP_STREAMS=0 enables it for experiments.
+        self.overlap_wgrad = False
+        import os
+        if os.environ.get("MAESTRO_GROUP_STREAMS") == "0":
+            self.group_streams = False
+        if os.environ.get("MAESTRO_WGRAD_OVERLAP") == "1" and not self.group_streams:
+            self.overlap_wgrad = True
         self._graphs, self._seen, self._ready_spans = {}, {}, []
+        self._events = []           # cross-stream ordering events of the current step (kept alive until the next step)
         self.side_streams = [torch.cuda.Stream(device=device) for _ in range(max(0, len(model.group_specs) - 1))]
         B = batch_size  # noqa: N806
         fold = m.fusion_mode in ("shared", "monotemp")
@@ -293,7 +353,7 @@ class MAEEngine:
 
     # ------------------------------------------------------------------------------------------ streams / graphs
     def _run_parallel(self, fns) -> None:
-        if len(fns) == 1 or not self.multi_stream:
+        if len(fns) == 1 or not self.multi_stream or not self.group_streams:
             for fn in fns:
                 fn()
             return
@@ -352,6 +412,7 @@ class MAEEngine:
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, batch: dict, noise: dict | None = None, struct: dict | None = None) -> torch.Tensor:
         """Runs the forward pass + loss; returns the loss as a 1-element device tensor (no host sync)."""
+        self._events.clear()        # outside any capture: safe point to release last step's events
         if self.store.refresh_half():
             self._pack_conv_weights()
         if noise is None or struct is None:
