@@ -157,6 +157,7 @@ def main() -> None:
         else:
             dist.init_process_group(args.backend)
 
+    torch.set_num_threads(min(4, host_cores()))   # host-side torch ops are tiny (mask draws); a 128-thread pool only adds latency
     torch.manual_seed(42 + rank)
     ds, model = build_model(args.config)
     loop = PretrainLoop(model, args.batch, dev, loss=args.loss, total_steps=args.steps + args.warmup, world_size=world)
@@ -175,6 +176,7 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = loop.step(batch)
+    t_issue = time.perf_counter() - t0   # host time to issue the steps (diagnostic: host-bound if ~= elapsed)
     sync()
     elapsed = time.perf_counter() - t0
     # Roofline leg: the same steps once more with HIP events around every MFMA-kernel launch on its stream (event
@@ -205,7 +207,7 @@ def main() -> None:
             "config": {"workload": f"{args.config}: {w['desc']}", "tiles_per_gpu": args.batch,
                        "global_batch": args.batch * world, "loss": args.loss, "fusion_mode": "group", "inter_depth": 3,
                        "parallelism": f"dp{world}", "params_M": round(loop.engine.store.total / 1e6, 1),
-                       "final_loss": round(loss_val, 5)},
+                       "final_loss": round(loss_val, 5), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3)},
             "whole_step": {"train_gflop_per_tile": w["gflop_tile"],
                            "mfma_frac": round(value / world * w["gflop_tile"] / 1e3 / MFMA_PEAK_TFLOPS, 4)},
         }

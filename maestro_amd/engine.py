@@ -25,6 +25,7 @@ from maestro_amd.layers.utils import draw_struct_masks
 
 F32, BF16, I32, U8 = torch.float32, torch.bfloat16, torch.int32, torch.uint8
 _NEVER = object()
+RING = 4  # pinned staging slots for the per-step mask uploads
 ALIGN = 64  # elements; keeps every parameter view 256-byte aligned
 
 
@@ -138,8 +139,10 @@ class Stack:
             hip.gemm(hip.GEMM_NT, M, dim, mlp, s["act"], mlp, ps.h(fc2.weight), mlp, x_out, dim,
                      hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=fc2.bias, res=x_mid, ldr=dim)
 
-    def backward(self, dx_out: torch.Tensor, dx_out16: torch.Tensor):
-        """``dx_out`` (f32) / ``dx_out16`` (bf16 copy): gradient w.r.t. ``x_last``.  Returns grad w.r.t. ``x0`` (f32).
+    def backward(self, dx_out: torch.Tensor, dx_out16: torch.Tensor, hi: int | None = None, lo: int = 0):
+        """``dx_out`` (f32) / ``dx_out16`` (bf16 copy): gradient w.r.t. the output of layer ``hi - 1`` (default: ``x_last``).
+        Processes layers ``hi-1 .. lo`` and returns ``(grad f32, grad bf16)`` w.r.t. the input of layer ``lo``
+        (``x0`` when ``lo == 0``); a range lets the engine cut the backward into several launch segments.
 
         The four weight-gradient GEMMs of a layer (+ the fc1 bias column sum) do not feed the dgrad chain, so they are
         issued on this stack's side stream and overlap the chain's non-MFMA kernels (attention backward, LayerNorm
@@ -179,7 +182,8 @@ class Stack:
 
         prev_fc1 = prev_proj = prev_qkv = None
         cur, cur16 = dx_out, dx_out16
-        for l in reversed(range(self.depth)):
+        hi = self.depth if hi is None else hi
+        for l in reversed(range(lo, hi)):
             attn, ff = self.t.layers[l]
             s, x_in, x_mid = self.saved[l], self.xs[2 * l], self.xs[2 * l + 1]
             ln2, fc1, fc2 = ff.net[0], ff.net[1], ff.net[4]
@@ -220,7 +224,7 @@ class Stack:
             eng._grads_ready(self.t.layers[l])
         if overlap:
             main.wait_stream(ws)   # join: all weight gradients of this stack are complete past this point
-        return cur
+        return cur, cur16
 
 
 # ======================================================================================= the engine
@@ -253,6 +257,9 @@ class MAEEngine:
         if os.environ.get("MAESTRO_WGRAD_OVERLAP") == "1" and not self.group_streams:
             self.overlap_wgrad = True
         self._graphs, self._seen, self._ready_spans = {}, {}, []
+        self._h2d_done = [None] * RING   # per ring slot: event after the mask uploads that last used it
+        self._step = 0
+        self._enc_state = {}        # per group: (grad f32, grad bf16) carried between encoder backward segments
         self._events = []           # cross-stream ordering events of the current step (kept alive until the next step)
         self.side_streams = [torch.cuda.Stream(device=device) for _ in range(max(0, len(model.group_specs) - 1))]
         B = batch_size  # noqa: N806
@@ -311,8 +318,9 @@ class MAEEngine:
             date_row = torch.cat([(s.date_off + torch.arange(s.n_tok) // s.L).to(I32) for s in g.mods])
             pos_dec = torch.cat([m.pos_dec_rows[s.name].repeat(s.D, 1) for s in g.mods], dim=0)
             self.gb[g.name] = dict(
-                xg=e(Bn, L, E), dxg=z(Bn, L, E), noise_h=torch.empty(Bn, L, dtype=F32).pin_memory(),
-                struct_h=torch.empty(Bn, L, dtype=U8).pin_memory(), noise=e(Bn, L), struct=e(Bn, L, dt=U8),
+                xg=e(Bn, L, E), dxg=z(Bn, L, E), noise_h=[torch.empty(Bn, L, dtype=F32).pin_memory() for _ in range(RING)],
+                struct_h=[torch.empty(Bn, L, dtype=U8).pin_memory() for _ in range(RING)], noise=e(Bn, L),
+                struct=e(Bn, L, dt=U8),
                 vis=e(Bn, N, dt=I32), msk=e(Bn, g.k, dt=I32), inv=e(Bn, L, dt=I32), mask=e(Bn, L, dt=U8),
                 dates=z(Bn, n_dates, 8), n_dates=n_dates, tok_slot=tok_slot.to(dev), date_row=date_row.to(dev),
                 pos_dec=pos_dec.to(dev).contiguous(), tok_table=e(len(g.mods), Dd),
@@ -419,12 +427,23 @@ class MAEEngine:
             n2, s2 = self.draw_masks()
             noise = noise if noise is not None else n2
             struct = struct if struct is not None else s2
-        for g in self.groups:  # host -> pinned -> device (outside any graph)
+        # host -> pinned ring slot -> device (outside any graph).  A slot is reused every RING steps; only then do we wait
+        # for the async copies that last read it (the host may run several steps ahead of the GPU, but a per-step
+        # hipEventSynchronize was measured to wake up ~10 ms late and starve the queue).
+        slot = self._step % RING
+        self._step += 1
+        if self._h2d_done[slot] is not None:
+            self._h2d_done[slot].synchronize()
+        for g in self.groups:
             gbuf = self.gb[g.name]
-            gbuf["noise_h"].copy_(noise[g.name])
-            gbuf["struct_h"].copy_(struct[g.name].reshape(g.Beff, g.L).to(U8))
-            gbuf["noise"].copy_(gbuf["noise_h"], non_blocking=True)
-            gbuf["struct"].copy_(gbuf["struct_h"], non_blocking=True)
+            nh, sh = gbuf["noise_h"][slot], gbuf["struct_h"][slot]
+            nh.copy_(noise[g.name])
+            sh.copy_(struct[g.name].reshape(g.Beff, g.L))
+            gbuf["noise"].copy_(nh, non_blocking=True)
+            gbuf["struct"].copy_(sh, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._h2d_done[slot] = ev
         batch = dict(batch)
         for s in self.mods.values():
             img = batch[s.name]
@@ -541,7 +560,13 @@ class MAEEngine:
         self._segment("bwd_dec", key, self._bwd_decoder_side)
         if self.joint is not None:
             self._segment("bwd_joint", key, self._bwd_joint)
-        self._segment("bwd_enc", key, self._bwd_encoder_side)
+        # encoder side: with a gradient hook (data parallel) cut it into layer ranges so the all-reduce of the finished
+        # slices overlaps the remaining layers (~85 % of the parameters live in the group encoders)
+        depth = max(st.depth for st in self.enc.values())
+        cuts = [depth, 0] if self.grad_hook is None or depth < 3 else [depth, depth - depth // 3, depth // 3, 0]
+        for i in range(len(cuts) - 1):
+            self._segment(f"bwd_enc{i}", key, lambda hi=cuts[i], lo=cuts[i + 1], first=(i == 0), last=(i == len(cuts) - 2):
+                          self._bwd_encoder_side(hi, lo, first, last))
 
     def _bwd_decoder_side(self) -> None:
         m, E, Dd, ps = self.model, self.E, self.Dd, self.store  # noqa: N806
@@ -564,7 +589,7 @@ class MAEEngine:
                                       None, dx, dx16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(), gbuf["ln_ws"],
                                       s.Beff, s.n_tok, Dd)
                     self._grads_ready(m.embed_to_rec[s.embed])
-                dx0 = st.backward(dx, dx16)
+                dx0, _ = st.backward(dx, dx16)
                 self._grads_ready(nrm)
                 # unmask backward: visible rows -> enc_to_dec output grad; masked rows -> mask-token grads
                 hip.gather_rows(dx0, gbuf["vis"], gbuf["dy_e2d"], g.Beff, g.L, g.N, Dd, g.N, 0)
@@ -591,10 +616,12 @@ class MAEEngine:
 
     def _bwd_joint(self) -> None:
         jt = self.joint
-        self._djoint = jt.backward(jt.dxa, jt.dxa16)
+        self._djoint, _ = jt.backward(jt.dxa, jt.dxa16)
         self._grads_ready(jt.t.norm)
 
-    def _bwd_encoder_side(self) -> None:
+    def _bwd_encoder_side(self, hi: int, lo: int, first: bool, last: bool) -> None:
+        """Layers ``hi-1 .. lo`` of every group encoder (groups on parallel streams); ``first`` also runs the final-LN
+        backward, ``last`` the scatter + patch-embed backward."""
         m, E, ps = self.model, self.E, self.store  # noqa: N806
         AT = hip.OUT_F32 | hip.ATOMIC  # noqa: N806
 
@@ -602,16 +629,23 @@ class MAEEngine:
             def run():
                 gbuf, st = self.gb[g.name], self.enc[g.name]
                 nrm = st.t.norm
-                if self.joint is not None:
-                    hip.layernorm_bwd(self._djoint, m.joint_N, g.joint_off, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"],
-                                      gbuf["rstd_e"], None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias),
-                                      st.top_bias_grad(), gbuf["ln_ws"], g.Beff, g.N, E)
-                else:
-                    hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"], gbuf["rstd_e"],
-                                      None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(),
-                                      gbuf["ln_ws"], g.Beff, g.N, E)
-                dx0 = st.backward(st.dxa, st.dxa16)
-                self._grads_ready(nrm)
+                s_hi, s_lo = min(hi, st.depth), min(lo, st.depth)
+                if first:
+                    if self.joint is not None:
+                        hip.layernorm_bwd(self._djoint, m.joint_N, g.joint_off, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"],
+                                          gbuf["rstd_e"], None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias),
+                                          st.top_bias_grad(), gbuf["ln_ws"], g.Beff, g.N, E)
+                    else:
+                        hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"],
+                                          gbuf["rstd_e"], None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias),
+                                          st.top_bias_grad(), gbuf["ln_ws"], g.Beff, g.N, E)
+                    self._grads_ready(nrm)
+                    self._enc_state[g.name] = (st.dxa, st.dxa16)
+                cur, cur16 = self._enc_state[g.name]
+                self._enc_state[g.name] = st.backward(cur, cur16, s_hi, s_lo)
+                if not last:
+                    return
+                dx0 = self._enc_state[g.name][0]
                 # scatter to the full group sequence (masked tokens get zero), then patch-embed backward per modality
                 gbuf["dxg"].zero_()
                 hip.scatter_rows(dx0, gbuf["vis"], gbuf["dxg"], g.Beff, g.L, g.N, E, g.N, 0)
@@ -629,8 +663,9 @@ class MAEEngine:
             return run
 
         self._run_parallel([side(g) for g in self.groups])
-        for name in m.patch_embed:
-            self._grads_ready(m.patch_embed[name])
+        if last:
+            for name in m.patch_embed:
+                self._grads_ready(m.patch_embed[name])
 
     # ------------------------------------------------------------------------------------------ outputs
     def reconstructions(self):
