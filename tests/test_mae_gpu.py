@@ -198,3 +198,44 @@ def test_segmented_backward_with_grad_hook_matches_unsegmented():
         assert covered[0][0] == 0 and covered[-1][1] == eng.store.total
         assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), "reported gradient slices overlap or leave gaps"
     assert {"bwd_enc0", "bwd_enc1", "bwd_enc2"} <= set(eng._graphs)
+
+
+def test_ssl_module_lightning_style_step(golden_dir):
+    """The drop-in surface as Lightning drives it: training_step -> loss.backward() -> torch optimizer step."""
+    from types import SimpleNamespace
+
+    from maestro_amd.train.model import SSLModule
+    from maestro_amd.train.trainer import synthetic_batch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    ds = conf.DatasetsConfig(name_dataset="treesatai_ts", treesatai_ts=conf.TreeSatAITSConfig(
+        filter_targets=[], aerial=conf.InputRasterConfig(image_size=60, patch_size=conf.PatchSizeConfig(mae=20), bands=4,
+                                                         norm_bands=[1, 3], norm_fac=255.0)))
+    torch.manual_seed(0)
+    mod = SSLModule(datasets=ds, mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=3,
+                    model="mae", model_size="tiny", loss="l1_norm", use_ema=False)
+    mod.trainer = SimpleNamespace(ssl_phase="pretrain", train_dataloader=SimpleNamespace(batch_size=2),
+                                  accumulate_grad_batches=1, num_nodes=1, num_devices=1, base_lr=3e-3, wd=0.01, b1=0.9, b2=0.99,
+                                  final_factor=1e7, estimated_stepping_batches=20, max_epochs=5)
+    batch = synthetic_batch(ds.dataset, 2, dev)
+    cfg = mod.configure_optimizers()
+    opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+    losses = []
+    for step in range(6):
+        torch.manual_seed(11)                      # same masks every step -> the loss must go down
+        out = mod.training_step(batch, step)
+        assert set(out) == {"loss", "log_inputs", "log_preds", "log_targets"} and out["loss"].requires_grad
+        opt.zero_grad(set_to_none=True)            # Lightning clears grads to None; backward must re-attach the views
+        out["loss"].backward()
+        eng = mod.model._engine
+        for p in eng.store.params:
+            assert p.grad is not None and p.grad.data_ptr() == eng.store.g(p).data_ptr()
+        opt.step()
+        sched.step()
+        losses.append(out["loss"].item())
+    assert losses[-1] < losses[0], losses
+    assert mod.metrics["loss_rec_train"].count == 6
+    name, make = next(iter(out["log_preds"].items()))
+    img = make()
+    assert name.startswith("pretrain_train/_aerial") and img.shape == (4, 60, 60)
