@@ -17,6 +17,8 @@ Pipeline (reference ``maestro/ssl/mim.py:473-505`` + ``maestro/train/model.py:19
 
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -251,7 +253,6 @@ class MAEEngine:
         # group streams alone (C3), and nesting both forks inside one hipGraph capture crashes hipStreamEndCapture
         # (ROCm 7.2) -> off by default; MAESTRO_WGRAD_OVERLAP=1 MAESTRO_GROUP_STREAMS=0 enables it for experiments.
         self.overlap_wgrad = False
-        import os
         if os.environ.get("MAESTRO_GROUP_STREAMS") == "0":
             self.group_streams = False
         if os.environ.get("MAESTRO_WGRAD_OVERLAP") == "1" and not self.group_streams:
@@ -290,7 +291,6 @@ class MAEEngine:
         self._alloc()
         self.store.refresh_half(force=True)
         self._pack_conv_weights()
-        self.step_count = 0
 
     # ------------------------------------------------------------------------------------------ allocation
     def _alloc(self) -> None:

@@ -1,7 +1,8 @@
 """ctypes binding of libmaestro_hip.so (the C ABI in include/maestro_hip.h) for torch device tensors.
 
 There is NO fallback: if the library is missing or a tensor is not on the GPU the call raises.  PyTorch is used
-only for device memory and the current HIP stream.
+only for device memory and the current HIP stream.  ``KernelTimer`` (bottom of the file) brackets the MFMA kernels
+with HIP events on their launch stream for bench.py's roofline leg.
 """
 
 from __future__ import annotations
