@@ -45,6 +45,23 @@ int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const 
                  int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                  int ldaux, void* stream);
 
+/* Same contract through the large-tile LDS-DMA kernel (256x256x32 tile, 4-stage LDS ring; gemm_dma.hip).  Returns -2
+ * when the problem does not qualify (K tail inside a K-minor operand, > 2 GiB operands): call mh_gemm_bf16 instead.
+ * mh_gemm_bf16 itself dispatches here for the shapes where this kernel is faster. */
+int mh_gemm_bf16_dma(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                     int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
+                     int ldaux, void* stream);
+
+/* Grouped weight-gradient GEMM: ONE launch over the 256x256 tiles of many independent "TN" problems
+ * dW_i[M_i, N_i] (f32, PLAIN stores) = A_i^T B_i with A_i [K_i, M_i] bf16 (= dY_i), B_i [K_i, N_i] bf16 (= X_i), K_i = tokens.
+ * Used to issue all wgrads of a backward segment at once (no split-K atomics, whole-chip tile occupancy).  `table` is a
+ * DEVICE array; tile_begin is the exclusive prefix sum of ceil(M/256)*ceil(N/256); M, N, lda, ldb %% 8 == 0. */
+typedef struct MhGroupedGemm {
+    const void* A; const void* B; void* C;
+    int M, N, K, lda, ldb, ldc, tile_begin, reserved;
+} MhGroupedGemm;
+int mh_gemm_grouped_tn(const MhGroupedGemm* table_device, int n_problems, int total_tiles, void* stream);
+
 /* ---------------------------------------------------------------------------------------------- LayerNorm
  * y = (x - mean) * rstd * gamma + beta over the last dim; x f32 (residual stream), y bf16 (GEMM operand) or f32.
  * Rows are addressed as row(b, j) = b * L + off + j (j < n) on both sides, so the split / concat of group sequences

@@ -10,22 +10,13 @@
 // The MFMA is issued with swapped operands (D' = B_tile * A_tile^T) so every lane owns 4 CONSECUTIVE output
 // columns of one row: bias/residual/aux are read and C is written with 8/16-byte vectors.
 // Split-K + fp32 atomics (LDS-transposed so each wave instruction adds 256 contiguous bytes) serve the wgrad.
-#include "common.hpp"
-#include "../../include/maestro_hip.h"
+#include "gemm_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
 constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile, 16 KiB
-
-struct GemmParams {
-    const bf16_t* A; const bf16_t* B; void* C;
-    const float* bias; const float* res; const bf16_t* aux_in; bf16_t* aux_out;
-    int M, N, K, lda, ldb, ldc, ldr, ldaux, flags;
-    int tiles_m, tiles_n, k_per_split;
-    int fast;               // 1: buffer-load path (no K tail inside a K-minor operand, extents < 2 GiB)
-    unsigned a_bytes, b_bytes;
-};
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
@@ -245,97 +236,29 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmParams p) {
         }
     }
 
-    const int g = l >> 4, lm = l & 15;
-    if (p.flags & MH_GEMM_ATOMIC) {
-        // Transpose each wave's 64x64 fp32 tile through LDS (operand buffers are free now; last loop barrier passed)
-        // so that one wave instruction adds one 256-B row segment.
-        // Per wave a 32x65 fp32 staging region (8.1 KiB), two passes of 32 rows.
-        float* st = reinterpret_cast<float*>(smem) + w * (32 * 65);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-#pragma unroll
-            for (int i = 2 * half; i < 2 * half + 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) st[(16 * (i - 2 * half) + lm) * 65 + 16 * j + 4 * g + r] = acc[j][i][r];
-            const int n = n0 + wn + l;
-            if (n < p.N) {
-                for (int rr = 0; rr < 32; ++rr) {
-                    const int m = m0 + wm + 32 * half + rr;
-                    if (m < p.M) atomicAdd(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, st[rr * 65 + l]);
-                }
-            }
-        }
-        return;
-    }
-
-    // Epilogue.  Each wave transposes its 64x64 fp32 tile through a private LDS region (two passes of 32 rows, 68-float
-    // row pitch: conflict-free ds_write_b128 / ds_read_b128) so that the bias / residual / aux reads and the C / aux
-    // writes are done in ROW-MAJOR lane order: 8 lanes cover one 128-byte row segment with 16-byte accesses.
-    const bool out_f32 = p.flags & MH_GEMM_OUT_F32;
+    // epilogues (gemm_common.hpp): operand buffers are free now (the last loop barrier has been passed); each wave stages
+    // through its private 32 x 68 float region
     float* st = reinterpret_cast<float*>(smem) + w * (32 * 68);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int i = 2 * half; i < 2 * half + 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<f32x4*>(st + (16 * (i - 2 * half) + lm) * 68 + 16 * j + 4 * g) = acc[j][i];
-        if (out_f32) {
-            const int c = (l & 15) * 4, n = n0 + wn + c;
-#pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
-                const int r = pass * 4 + (l >> 4), m = m0 + wm + 32 * half + r;
-                f32x4 v = *reinterpret_cast<const f32x4*>(st + r * 68 + c);
-                if (m < p.M && n < p.N) {
-                    if (p.flags & MH_GEMM_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    if (p.flags & MH_GEMM_RESIDUAL) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n);
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
-                }
-            }
-        } else {
-            const int c = (l & 7) * 8, n = n0 + wn + c;
-            f32x4 b_lo = {0, 0, 0, 0}, b_hi = {0, 0, 0, 0};
-            if ((p.flags & MH_GEMM_BIAS) && n < p.N) {
-                b_lo = *reinterpret_cast<const f32x4*>(p.bias + n);
-                b_hi = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-            }
-#pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int r = pass * 8 + (l >> 3), m = m0 + wm + 32 * half + r;
-                f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * 68 + c);
-                f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * 68 + c + 4);
-                if (m < p.M && n < p.N) {
-                    lo += b_lo; hi += b_hi;
-                    if (p.flags & MH_GEMM_GELU) {
-                        if (p.aux_out) {
-                            u32x4 pk = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
-                            *reinterpret_cast<u32x4*>(p.aux_out + (size_t)m * p.ldaux + n) = pk;
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { lo[e] = gelu_erf(lo[e]); hi[e] = gelu_erf(hi[e]); }
-                    }
-                    if (p.flags & MH_GEMM_DGELU) {
-                        const u32x4 pk = *reinterpret_cast<const u32x4*>(p.aux_in + (size_t)m * p.ldaux + n);
-                        lo[0] *= gelu_erf_grad(__uint_as_float(pk[0] << 16));
-                        lo[1] *= gelu_erf_grad(__uint_as_float(pk[0] & 0xffff0000u));
-                        lo[2] *= gelu_erf_grad(__uint_as_float(pk[1] << 16));
-                        lo[3] *= gelu_erf_grad(__uint_as_float(pk[1] & 0xffff0000u));
-                        hi[0] *= gelu_erf_grad(__uint_as_float(pk[2] << 16));
-                        hi[1] *= gelu_erf_grad(__uint_as_float(pk[2] & 0xffff0000u));
-                        hi[2] *= gelu_erf_grad(__uint_as_float(pk[3] << 16));
-                        hi[3] *= gelu_erf_grad(__uint_as_float(pk[3] & 0xffff0000u));
-                    }
-                    u32x4 pk = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
-                }
-            }
-        }
-    }
+    if (p.flags & MH_GEMM_ATOMIC) gemm_epilogue_atomic<4>(p, acc, st, m0 + wm, n0 + wn);
+    else gemm_epilogue_store<4>(p, acc, st, m0 + wm, n0 + wn);
 }
 
 }  // namespace
+
+// Dispatch rule for the large-tile LDS-DMA kernel (gemm_dma.hip), from scripts/bench_gemm3.py on MI355X: it wins (x1.10 to
+// x1.35) for NT problems whose 256x256 tiles fill the 256 CUs in whole waves (>= 90 % wave efficiency); it loses when the
+// tile count quantises badly (M = 8192 encoder shapes), for K-major operands and for split-K wgrads (more splits -> more
+// fp32 atomic passes).  MH_GEMM_DMA=0 disables it, MH_GEMM_DMA=1 forces it wherever it is eligible (experiments).
+static bool prefer_dma(int layout, int M, int N, int K, int flags) {
+    const char* e = getenv("MH_GEMM_DMA");
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '1') return true;
+    if (layout != 0 || (flags & MH_GEMM_ATOMIC) || K % 32 != 0 || K < 256) return false;
+    const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256);
+    if (tiles < 256) return false;
+    const long waves = (tiles + 255) / 256;
+    return 10 * tiles >= 9 * 256 * waves;
+}
 
 extern "C" int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                             int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in,
@@ -363,6 +286,11 @@ extern "C" int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int 
     MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || !(flags & ~(MH_GEMM_ATOMIC | MH_GEMM_OUT_F32)),
                  "mh_gemm_bf16: atomic accumulate excludes other epilogues");
 
+    if (prefer_dma(layout, M, N, K, flags)) {
+        const int rc = mh_gemm_bf16_dma(layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux,
+                                        stream);
+        if (rc != -2) return rc;   // -2: not eligible -> general kernel below
+    }
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
     p.bias = bias; p.res = res; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out;

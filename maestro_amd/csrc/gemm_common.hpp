@@ -1,0 +1,108 @@
+// Pieces shared by the two GEMM kernels (gemm.hip: 128x128 register-staged; gemm_dma.hip: 256x256 LDS-DMA ring):
+// the parameter block and the LDS-staged epilogues for a wave tile of (16*MT) x 64 accumulators held as acc[j][i]
+// (j = n-tile 0..3, i = m-tile 0..MT-1; lane owns rows 16i + (lane&15), columns 16j + 4*(lane>>4) .. +3).
+#pragma once
+#include "common.hpp"
+#include "../../include/maestro_hip.h"
+
+struct GemmParams {
+    const bf16_t* A; const bf16_t* B; void* C;
+    const float* bias; const float* res; const bf16_t* aux_in; bf16_t* aux_out;
+    int M, N, K, lda, ldb, ldc, ldr, ldaux, flags;
+    int tiles_m, tiles_n, k_per_split;
+    int fast;               // 1: buffer-load path (no K tail inside a K-minor operand, extents < 2 GiB)
+    unsigned a_bytes, b_bytes;
+};
+
+
+// Row-major epilogue: each wave transposes its tile through a private LDS region (passes of 32 rows, 68-float row pitch:
+// conflict-free ds_write_b128 / ds_read_b128) so that the bias / residual / aux reads and the C / aux writes are done in
+// ROW-MAJOR lane order: 8 lanes cover one 128-byte row segment with 16-byte accesses.
+template <int MT>
+__device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f32x4 (&acc)[4][MT], float* st, int m_base,
+                                                    int n_base) {
+    const int l = threadIdx.x & 63, g = l >> 4, lm = l & 15;
+    const bool out_f32 = p.flags & MH_GEMM_OUT_F32;
+#pragma unroll
+    for (int pass_m = 0; pass_m < MT / 2; ++pass_m) {
+#pragma unroll
+        for (int i = 2 * pass_m; i < 2 * pass_m + 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(st + (16 * (i - 2 * pass_m) + lm) * 68 + 16 * j + 4 * g) = acc[j][i];
+        if (out_f32) {
+            const int c = (l & 15) * 4, n = n_base + c;
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int r = pass * 4 + (l >> 4), m = m_base + 32 * pass_m + r;
+                f32x4 v = *reinterpret_cast<const f32x4*>(st + r * 68 + c);
+                if (m < p.M && n < p.N) {
+                    if (p.flags & MH_GEMM_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (p.flags & MH_GEMM_RESIDUAL) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n);
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
+                }
+            }
+        } else {
+            const int c = (l & 7) * 8, n = n_base + c;
+            f32x4 b_lo = {0, 0, 0, 0}, b_hi = {0, 0, 0, 0};
+            if ((p.flags & MH_GEMM_BIAS) && n < p.N) {
+                b_lo = *reinterpret_cast<const f32x4*>(p.bias + n);
+                b_hi = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+            }
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int r = pass * 8 + (l >> 3), m = m_base + 32 * pass_m + r;
+                f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * 68 + c);
+                f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * 68 + c + 4);
+                if (m < p.M && n < p.N) {
+                    lo += b_lo; hi += b_hi;
+                    if (p.flags & MH_GEMM_GELU) {
+                        if (p.aux_out) {
+                            u32x4 pk = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+                            *reinterpret_cast<u32x4*>(p.aux_out + (size_t)m * p.ldaux + n) = pk;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { lo[e] = gelu_erf(lo[e]); hi[e] = gelu_erf(hi[e]); }
+                    }
+                    if (p.flags & MH_GEMM_DGELU) {
+                        const u32x4 pk = *reinterpret_cast<const u32x4*>(p.aux_in + (size_t)m * p.ldaux + n);
+                        lo[0] *= gelu_erf_grad(__uint_as_float(pk[0] << 16));
+                        lo[1] *= gelu_erf_grad(__uint_as_float(pk[0] & 0xffff0000u));
+                        lo[2] *= gelu_erf_grad(__uint_as_float(pk[1] << 16));
+                        lo[3] *= gelu_erf_grad(__uint_as_float(pk[1] & 0xffff0000u));
+                        hi[0] *= gelu_erf_grad(__uint_as_float(pk[2] << 16));
+                        hi[1] *= gelu_erf_grad(__uint_as_float(pk[2] & 0xffff0000u));
+                        hi[2] *= gelu_erf_grad(__uint_as_float(pk[3] << 16));
+                        hi[3] *= gelu_erf_grad(__uint_as_float(pk[3] & 0xffff0000u));
+                    }
+                    u32x4 pk = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
+                }
+            }
+        }
+    }
+}
+
+// Split-K / accumulate epilogue: fp32 atomic adds, transposed through the same LDS region (65-float pitch) so that one
+// wave instruction adds one 256-byte row segment.
+template <int MT>
+__device__ __forceinline__ void gemm_epilogue_atomic(const GemmParams& p, const f32x4 (&acc)[4][MT], float* st, int m_base,
+                                                     int n_base) {
+    const int l = threadIdx.x & 63, g = l >> 4, lm = l & 15;
+#pragma unroll
+    for (int pass_m = 0; pass_m < MT / 2; ++pass_m) {
+#pragma unroll
+        for (int i = 2 * pass_m; i < 2 * pass_m + 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[(16 * (i - 2 * pass_m) + lm) * 65 + 16 * j + 4 * g + r] = acc[j][i][r];
+        const int n = n_base + l;
+        if (n < p.N) {
+            for (int rr = 0; rr < 32; ++rr) {
+                const int m = m_base + 32 * pass_m + rr;
+                if (m < p.M) atomicAdd(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, st[rr * 65 + l]);
+            }
+        }
+    }
+}

@@ -58,7 +58,14 @@ _I, _F, _L = ctypes.c_int, ctypes.c_float, ctypes.c_long
 
 
 def gemm(layout: int, M: int, N: int, K: int, A, lda: int, B, ldb: int, C, ldc: int, flags: int = 0, bias=None,
-         res=None, ldr: int = 0, aux_in=None, aux_out=None, ldaux: int = 0) -> None:
+         res=None, ldr: int = 0, aux_in=None, aux_out=None, ldaux: int = 0, impl: str = "auto") -> None:
+    if impl == "dma":   # force the large-tile LDS-DMA kernel (tests / micro-benchmarks)
+        rc = lib().mh_gemm_bf16_dma(_I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C), _I(ldc),
+                                    _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux), stream())
+        if rc == -2:
+            raise HipExtensionError("mh_gemm_bf16_dma: problem does not qualify for the DMA kernel")
+        _check(rc, "mh_gemm_bf16_dma")
+        return
     _check(lib().mh_gemm_bf16(_I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C), _I(ldc),
                               _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux),
                               stream()), "mh_gemm_bf16")
@@ -239,6 +246,19 @@ _timer: KernelTimer | None = None
 _GEMM_KERNEL = {GEMM_NT: "gemm_kernel<NT>", GEMM_NN: "gemm_kernel<NN>", GEMM_TN: "gemm_kernel<TN>"}
 
 
+def _uses_dma(layout, M, N, K, flags) -> bool:
+    """Mirror of prefer_dma() in csrc/gemm.hip (only used to label kernel timings)."""
+    import os
+    e = os.environ.get("MH_GEMM_DMA", "")
+    if e[:1] == "0":
+        return False
+    if layout != GEMM_NT or (flags & ATOMIC) or K % 32 or K < 256:
+        return False
+    tiles = -(-M // 256) * -(-N // 256)
+    waves = -(-tiles // 256)
+    return tiles >= 256 and 10 * tiles >= 9 * 256 * waves
+
+
 def set_kernel_timer(t: KernelTimer | None) -> None:
     global _timer
     _timer = t
@@ -255,7 +275,9 @@ _attn_fwd_raw, _attn_bwd_raw = attn_fwd, attn_bwd
 def gemm(layout, M, N, K, *a, **k):  # noqa: F811
     if _timer is None:
         return _gemm_raw(layout, M, N, K, *a, **k)
-    e0, e1 = _timer.record(_GEMM_KERNEL[layout], 2.0 * M * N * K, (M, N, K))
+    flags = a[6] if len(a) > 6 else k.get("flags", 0)
+    kind = "gemm_dma_kernel<NT>" if _uses_dma(layout, M, N, K, flags) else _GEMM_KERNEL[layout]
+    e0, e1 = _timer.record(kind, 2.0 * M * N * K, (M, N, K))
     e0.record()
     _gemm_raw(layout, M, N, K, *a, **k)
     e1.record()
@@ -277,3 +299,41 @@ def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):  # noqa: F811
     e0.record()
     _attn_bwd_raw(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale)
     e1.record()
+
+
+# ------------------------------------------------------------------------------------------------ grouped wgrad
+class _MhGroupedGemm(ctypes.Structure):
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("M", ctypes.c_int),
+                ("N", ctypes.c_int), ("K", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int),
+                ("tile_begin", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+class GroupedTN:
+    """Descriptor table (built once: all buffers are static) for ``mh_gemm_grouped_tn``: every entry is one
+    dW[M, N] (f32, plain store) = A[K, M]^T B[K, N] problem; the launch covers all their 256x256 tiles."""
+
+    def __init__(self, problems, device) -> None:
+        arr = (_MhGroupedGemm * len(problems))()
+        tiles = 0
+        self.keep = []
+        for i, (A, B, C, M, N, K, lda, ldb, ldc) in enumerate(problems):
+            if M % 8 or N % 8 or lda % 8 or ldb % 8 or ldc % 4:
+                raise HipExtensionError(f"grouped wgrad problem {i}: M, N, lda, ldb must be multiples of 8 ({M}, {N}, {lda}, {ldb})")
+            if C.dtype != torch.float32 or A.dtype != torch.bfloat16 or B.dtype != torch.bfloat16:
+                raise HipExtensionError("grouped wgrad: A, B bf16 and C f32 expected")
+            arr[i] = _MhGroupedGemm(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, lda, ldb, ldc, tiles, 0)
+            tiles += -(-M // 256) * -(-N // 256)
+            self.keep += [A, B, C]
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = raw.to(device)
+        self.n, self.tiles = len(problems), tiles
+        self.flops = sum(2.0 * M * N * K for (_, _, _, M, N, K, _, _, _) in problems)
+
+    def launch(self) -> None:
+        if _timer is None:
+            call("mh_gemm_grouped_tn", self.table, _I(self.n), _I(self.tiles))
+            return
+        e0, e1 = _timer.record("gemm_dma_grouped_tn_kernel", self.flops, ("grouped", self.n, self.tiles))
+        e0.record()
+        call("mh_gemm_grouped_tn", self.table, _I(self.n), _I(self.tiles))
+        e1.record()

@@ -1,11 +1,14 @@
-import sys, torch
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maestro_amd import hip
 dev = torch.device("cuda:0")
 layout, M, N, K = (int(x) for x in sys.argv[1:5])
+impl = sys.argv[5] if len(sys.argv) > 5 else "v1"
 A = torch.randn((M, K) if layout < 2 else (K, M), device=dev).bfloat16()
 B = torch.randn((N, K) if layout == 0 else (K, N), device=dev).bfloat16()
 C = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
-for _ in range(30):
-    hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], C, N, 0)
+os.environ["MH_GEMM_DMA"] = "0"
+kw = {"impl": "dma"} if impl == "dma" else {}
+for _ in range(20):
+    hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], C, N, 0, **kw)
 torch.cuda.synchronize()
