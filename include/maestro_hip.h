@@ -53,12 +53,14 @@ int mh_gemm_bf16_dma(int layout, int M, int N, int K, const void* A, int lda, co
                      int ldaux, void* stream);
 
 /* Grouped weight-gradient GEMM: ONE launch over the 256x256 tiles of many independent "TN" problems
- * dW_i[M_i, N_i] (f32, PLAIN stores) = A_i^T B_i with A_i [K_i, M_i] bf16 (= dY_i), B_i [K_i, N_i] bf16 (= X_i), K_i = tokens.
- * Used to issue all wgrads of a backward segment at once (no split-K atomics, whole-chip tile occupancy).  `table` is a
- * DEVICE array; tile_begin is the exclusive prefix sum of ceil(M/256)*ceil(N/256); M, N, lda, ldb %% 8 == 0. */
+ * dW_i[M_i, N_i] (f32) = A_i^T B_i with A_i [K_i, M_i] bf16 (= dY_i), B_i [K_i, N_i] bf16 (= X_i), K_i = tokens.
+ * Used to issue all wgrads of a backward segment at once (no split-K, whole-chip tile occupancy).  `table` is a DEVICE
+ * array; tile_begin is the exclusive prefix sum of ceil(M/256)*ceil(N/256); M, N, lda, ldb %% 8 == 0.  accumulate = 0:
+ * plain stores (the entry is the only writer of C); 1: fp32 atomic adds into a zeroed C (several entries share one C,
+ * e.g. one encoder applied to several groups). */
 typedef struct MhGroupedGemm {
     const void* A; const void* B; void* C;
-    int M, N, K, lda, ldb, ldc, tile_begin, reserved;
+    int M, N, K, lda, ldb, ldc, tile_begin, accumulate;
 } MhGroupedGemm;
 int mh_gemm_grouped_tn(const MhGroupedGemm* table_device, int n_problems, int total_tiles, void* stream);
 

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_dma_grouped_tn_kernel(const MhGrou
     p.A = (const bf16_t*)g.A; p.B = (const bf16_t*)g.B; p.C = g.C;
     p.bias = nullptr; p.res = nullptr; p.aux_in = nullptr; p.aux_out = nullptr;
     p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.ldr = 0; p.ldaux = 0;
-    p.flags = MH_GEMM_OUT_F32;
+    p.flags = MH_GEMM_OUT_F32 | (g.accumulate ? MH_GEMM_ATOMIC : 0);
     p.tiles_m = (g.M + BM - 1) / BM; p.tiles_n = (g.N + BN - 1) / BN; p.k_per_split = g.K; p.fast = 1;
     p.a_bytes = (unsigned)(((long)(g.K - 1) * g.lda + g.M) * 2);
     p.b_bytes = (unsigned)(((long)(g.K - 1) * g.ldb + g.N) * 2);

@@ -103,13 +103,16 @@ class Stack:
                 mean1=e(M), rstd1=e(M), mean2=e(M), rstd2=e(M), h1=e(M, dim, dt=BF16), qkv=e(M, 3 * self.inner, dt=BF16),
                 o=e(M, self.inner, dt=BF16), lse=e(Bn * self.H * N), h2=e(M, dim, dt=BF16),
                 hpre=e(M, mlp, dt=BF16), act=e(M, mlp, dt=BF16)))
-        # backward scratch (shared by all layers)
+        # backward: the bf16 operands of the weight-gradient GEMMs persist per layer (dY of the layer output, dY of the
+        # attention residual, d fc1-out, d qkv) so that the wgrads can be deferred into one grouped launch per segment;
+        # the fp32 residual gradient ping-pongs between two shared buffers.
+        for s in self.saved:
+            s.update(gy16=e(M, dim, dt=BF16), gmid16=e(M, dim, dt=BF16), dh=e(M, mlp, dt=BF16),
+                     dqkv=e(M, 3 * self.inner, dt=BF16))
         self.dxa, self.dxb = e(M, dim), e(M, dim)
-        self.dxa16, self.dxb16 = e(M, dim, dt=BF16), e(M, dim, dt=BF16)
-        self.dh, self.dh2 = e(M, mlp, dt=BF16), e(M, dim, dt=BF16)
-        self.do, self.dqkv, self.delta = e(M, self.inner, dt=BF16), e(M, 3 * self.inner, dt=BF16), e(Bn * self.H * N)
+        self.dx0_16 = e(M, dim, dt=BF16)                                  # bf16 gradient w.r.t. x0
+        self.dh2, self.do, self.delta = e(M, dim, dt=BF16), e(M, self.inner, dt=BF16), e(Bn * self.H * N)
         self.ln_ws = e(max(1, hip.layernorm_bwd_workspace(M, dim)))  # private: stacks of different groups run concurrently
-        self.wstream = torch.cuda.Stream(device=dev)                 # side stream for the weight-gradient GEMMs
 
     @property
     def x0(self):
@@ -118,6 +121,11 @@ class Stack:
     @property
     def x_last(self):
         return self.xs[-1]
+
+    @property
+    def top16(self):
+        """bf16 buffer the producer of d ``x_last`` (the final-LN backward) must write next to the fp32 ``dxa``."""
+        return self.saved[-1]["gy16"] if self.depth else self.dx0_16
 
     def top_bias_grad(self):
         """Gradient slot of the last layer's fc2 bias: it equals colsum(d x_last), produced by the final-LN backward."""
@@ -141,91 +149,69 @@ class Stack:
             hip.gemm(hip.GEMM_NT, M, dim, mlp, s["act"], mlp, ps.h(fc2.weight), mlp, x_out, dim,
                      hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=fc2.bias, res=x_mid, ldr=dim)
 
-    def backward(self, dx_out: torch.Tensor, dx_out16: torch.Tensor, hi: int | None = None, lo: int = 0):
-        """``dx_out`` (f32) / ``dx_out16`` (bf16 copy): gradient w.r.t. the output of layer ``hi - 1`` (default: ``x_last``).
-        Processes layers ``hi-1 .. lo`` and returns ``(grad f32, grad bf16)`` w.r.t. the input of layer ``lo``
-        (``x0`` when ``lo == 0``); a range lets the engine cut the backward into several launch segments.
+    def wgrad_problems(self, lo: int = 0, hi: int | None = None) -> list:
+        """The four weight-gradient GEMMs dW[out, in] = dY[M, out]^T X[M, in] of layers ``lo .. hi-1`` as
+        ``hip.GroupedTN`` entries ``(A, B, C, M, N, K, lda, ldb, ldc)``; all operands are static buffers."""
+        ps, M = self.eng.store, self.M  # noqa: N806
+        dim, mlp, inner = self.dim, self.mlp, self.inner
+        out = []
+        for l in range(lo, self.depth if hi is None else hi):
+            attn, ff = self.t.layers[l]
+            s, fc1, fc2, proj = self.saved[l], ff.net[1], ff.net[4], attn.to_out[0]
+            out += [(s["gy16"], s["act"], ps.g(fc2.weight), dim, mlp, M, dim, mlp, mlp),
+                    (s["dh"], s["h2"], ps.g(fc1.weight), mlp, dim, M, mlp, dim, dim),
+                    (s["gmid16"], s["o"], ps.g(proj.weight), dim, inner, M, dim, inner, inner),
+                    (s["dqkv"], s["h1"], ps.g(attn.to_qkv.weight), 3 * inner, dim, M, 3 * inner, dim, dim)]
+        return out
 
-        The four weight-gradient GEMMs of a layer (+ the fc1 bias column sum) do not feed the dgrad chain, so they are
-        issued on this stack's side stream and overlap the chain's non-MFMA kernels (attention backward, LayerNorm
-        backward).  Scratch buffers are shared by all layers, hence the explicit ordering:
-          side waits  : e0 (layer input dY ready), e1 (dh), e2 (d x_mid), e3 (dqkv)          -- producers on the main stream
-          main joins the side stream once per layer, before LN1-bwd (which rewrites the dY buffer; the next layer then
-          rewrites dh / d x_mid / dqkv).  (A finer scheme with cross-layer event waits crashed hipStreamEndCapture.)
+    def backward(self, dx_out: torch.Tensor, hi: int | None = None, lo: int = 0, defer: bool = False):
+        """``dx_out`` (f32; its bf16 copy must already be in ``saved[hi-1]["gy16"]``, see ``top16``): gradient w.r.t. the
+        output of layer ``hi - 1`` (default ``x_last``).  Processes layers ``hi-1 .. lo`` and returns ``(grad f32, grad bf16)``
+        w.r.t. the input of layer ``lo`` (``x0`` when ``lo == 0``); a range lets the engine cut the backward into several
+        launch segments.
+
+        ``defer=False``: the four weight-gradient GEMMs of a layer are issued in line (split-K, fp32 atomics).
+        ``defer=True``: only the dgrad chain runs; the caller launches ``wgrad_problems(lo, hi)`` later as one grouped GEMM
+        (plain stores: the grouped launch must be the only writer of those weight-gradient slots in the step).
         """
         eng, ps, M = self.eng, self.eng.store, self.M  # noqa: N806
         dim, mlp, inner = self.dim, self.mlp, self.inner
         AT = hip.OUT_F32 | hip.ATOMIC  # noqa: N806
-        overlap = eng.multi_stream and eng.overlap_wgrad and self.depth > 0
-        main = torch.cuda.current_stream()
-        ws = self.wstream
-
-        def mark():  # event recorded on the main stream at this point
-            ev = torch.cuda.Event()
-            eng._events.append(ev)   # must outlive an ongoing hipGraph capture (destroying it mid-capture crashes HIP)
-            ev.record(main)
-            return ev
-
-        def side(after, fn):  # run fn on the side stream once `after` (main-stream event) has happened
-            if not overlap:
-                fn()
-                return None
-            ws.wait_event(after)
-            with torch.cuda.stream(ws):
-                fn()
-                ev = torch.cuda.Event()
-                eng._events.append(ev)
-                ev.record(ws)
-            return ev
-
-        def wait(ev):
-            if ev is not None:
-                main.wait_event(ev)
-
-        prev_fc1 = prev_proj = prev_qkv = None
-        cur, cur16 = dx_out, dx_out16
+        cur = dx_out
         hi = self.depth if hi is None else hi
+        cur16 = self.saved[hi - 1]["gy16"] if hi > 0 else self.dx0_16
         for l in reversed(range(lo, hi)):
             attn, ff = self.t.layers[l]
             s, x_in, x_mid = self.saved[l], self.xs[2 * l], self.xs[2 * l + 1]
             ln2, fc1, fc2 = ff.net[0], ff.net[1], ff.net[4]
             proj = attn.to_out[0]
-            mid, mid16 = (self.dxa, self.dxa16) if cur is not self.dxa else (self.dxb, self.dxb16)
-            nxt, nxt16 = (self.dxa, self.dxa16) if mid is not self.dxa else (self.dxb, self.dxb16)
+            cur16, mid16, dh, dqkv = s["gy16"], s["gmid16"], s["dh"], s["dqkv"]
+            mid = self.dxa if cur is not self.dxa else self.dxb
+            nxt = self.dxa if mid is not self.dxa else self.dxb
+            nxt16 = self.saved[l - 1]["gy16"] if l > 0 else self.dx0_16
             # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-            e0 = mark() if overlap else None
-            hip.gemm(hip.GEMM_NN, M, mlp, dim, cur16, dim, ps.h(fc2.weight), mlp, self.dh, mlp, hip.DGELU,
-                     aux_in=s["hpre"], ldaux=mlp)
-            e1 = mark() if overlap else None
-            ev_fc2 = side(e0, lambda: hip.gemm(hip.GEMM_TN, dim, mlp, M, cur16, dim, s["act"], mlp, ps.g(fc2.weight), mlp, AT))
-
-            def fc1_grads():
-                hip.gemm(hip.GEMM_TN, mlp, dim, M, self.dh, mlp, s["h2"], dim, ps.g(fc1.weight), dim, AT)
-                hip.colsum(self.dh, ps.g(fc1.bias), M, mlp, mlp)
-            prev_fc1 = side(e1, fc1_grads)
-            hip.gemm(hip.GEMM_NN, M, dim, mlp, self.dh, mlp, ps.h(fc1.weight), dim, self.dh2, dim)
+            hip.gemm(hip.GEMM_NN, M, mlp, dim, cur16, dim, ps.h(fc2.weight), mlp, dh, mlp, hip.DGELU, aux_in=s["hpre"],
+                     ldaux=mlp)
+            if not defer:
+                hip.gemm(hip.GEMM_TN, dim, mlp, M, cur16, dim, s["act"], mlp, ps.g(fc2.weight), mlp, AT)
+                hip.gemm(hip.GEMM_TN, mlp, dim, M, dh, mlp, s["h2"], dim, ps.g(fc1.weight), dim, AT)
+            hip.colsum(dh, ps.g(fc1.bias), M, mlp, mlp)
+            hip.gemm(hip.GEMM_NN, M, dim, mlp, dh, mlp, ps.h(fc1.weight), dim, self.dh2, dim)
             hip.layernorm_bwd(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16,
                               ps.g(ln2.weight), ps.g(ln2.bias), ps.g(proj.bias), self.ln_ws, 1, M, dim)
             # ---- attention: x_mid = x_in + proj(attn(qkv(LN1(x_in))))
-            e2 = mark() if overlap else None
             hip.gemm(hip.GEMM_NN, M, inner, dim, mid16, dim, ps.h(proj.weight), inner, self.do, inner)
-            prev_proj = side(e2, lambda: hip.gemm(hip.GEMM_TN, dim, inner, M, mid16, dim, s["o"], inner, ps.g(proj.weight),
-                                                  inner, AT))
-            hip.attn_bwd(s["qkv"], s["o"], self.do, s["lse"], self.delta, self.dqkv, self.Bn, self.N, self.H, self.Dh,
-                         attn.scale)
-            e3 = mark() if overlap else None
-            prev_qkv = side(e3, lambda: hip.gemm(hip.GEMM_TN, 3 * inner, dim, M, self.dqkv, 3 * inner, s["h1"], dim,
-                                                 ps.g(attn.to_qkv.weight), dim, AT))
-            hip.gemm(hip.GEMM_NN, M, dim, 3 * inner, self.dqkv, 3 * inner, ps.h(attn.to_qkv.weight), dim, self.dh2, dim)
+            if not defer:
+                hip.gemm(hip.GEMM_TN, dim, inner, M, mid16, dim, s["o"], inner, ps.g(proj.weight), inner, AT)
+            hip.attn_bwd(s["qkv"], s["o"], self.do, s["lse"], self.delta, dqkv, self.Bn, self.N, self.H, self.Dh, attn.scale)
+            if not defer:
+                hip.gemm(hip.GEMM_TN, 3 * inner, dim, M, dqkv, 3 * inner, s["h1"], dim, ps.g(attn.to_qkv.weight), dim, AT)
+            hip.gemm(hip.GEMM_NN, M, dim, 3 * inner, dqkv, 3 * inner, ps.h(attn.to_qkv.weight), dim, self.dh2, dim)
             prev_fc2_bias = ps.g(self.t.layers[l - 1][1].net[4].bias) if l > 0 else None  # = colsum(dx_out of layer l-1)
-            if overlap:
-                main.wait_stream(ws)   # join per layer: LN1-bwd rewrites dY (bf16) and the next layer rewrites dh / d x_mid / dqkv
             hip.layernorm_bwd(self.dh2, M, 0, x_in, M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid, nxt, nxt16,
                               ps.g(attn.norm.weight), ps.g(attn.norm.bias), prev_fc2_bias, self.ln_ws, 1, M, dim)
             cur, cur16 = nxt, nxt16
             eng._grads_ready(self.t.layers[l])
-        if overlap:
-            main.wait_stream(ws)   # join: all weight gradients of this stack are complete past this point
         return cur, cur16
 
 
@@ -249,19 +235,19 @@ class MAEEngine:
         self.use_graphs = True      # capture launch segments into hipGraphs once input addresses repeat
         self.multi_stream = True    # independent groups on parallel HIP streams
         self.group_streams = True   # (only with multi_stream) groups on parallel streams
-        # Weight-gradient GEMMs on a side stream per transformer stack: measured 31.1 ms/step alone vs 25.7 ms/step for
-        # group streams alone (C3), and nesting both forks inside one hipGraph capture crashes hipStreamEndCapture
-        # (ROCm 7.2) -> off by default; MAESTRO_WGRAD_OVERLAP=1 MAESTRO_GROUP_STREAMS=0 enables it for experiments.
-        self.overlap_wgrad = False
+        # Weight gradients of the transformer stacks: "fused" = in line with the dgrad chain (split-K, fp32 atomics);
+        # "deferred" = one grouped large-tile launch per backward segment (per step without a gradient hook);
+        # "auto" = deferred where the launch has enough 256x256 tiles to fill the chip (see _wgrad_plan).
+        self.wgrad_mode = os.environ.get("MAESTRO_WGRAD", "auto")
+        if self.wgrad_mode not in ("auto", "fused", "deferred"):
+            raise ValueError(f"MAESTRO_WGRAD={self.wgrad_mode!r}: expected auto, fused or deferred")
+        self._wgrad_tables, self._wgrad_plans = {}, {}
         if os.environ.get("MAESTRO_GROUP_STREAMS") == "0":
             self.group_streams = False
-        if os.environ.get("MAESTRO_WGRAD_OVERLAP") == "1" and not self.group_streams:
-            self.overlap_wgrad = True
         self._graphs, self._seen, self._ready_spans = {}, {}, []
         self._h2d_done = [None] * RING   # per ring slot: event after the mask uploads that last used it
         self._step = 0
         self._enc_state = {}        # per group: (grad f32, grad bf16) carried between encoder backward segments
-        self._events = []           # cross-stream ordering events of the current step (kept alive until the next step)
         self.side_streams = [torch.cuda.Stream(device=device) for _ in range(max(0, len(model.group_specs) - 1))]
         B = batch_size  # noqa: N806
         fold = m.fusion_mode in ("shared", "monotemp")
@@ -420,7 +406,6 @@ class MAEEngine:
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, batch: dict, noise: dict | None = None, struct: dict | None = None) -> torch.Tensor:
         """Runs the forward pass + loss; returns the loss as a 1-element device tensor (no host sync)."""
-        self._events.clear()        # outside any capture: safe point to release last step's events
         if self.store.refresh_half():
             self._pack_conv_weights()
         if noise is None or struct is None:
@@ -548,24 +533,79 @@ class MAEEngine:
     def zero_grad(self) -> None:
         self.store.grad.zero_()
 
-    def backward(self, grad_scale: float = 1.0) -> None:
-        """Backward of the last ``forward`` (d loss = 1); accumulates into the flat grad buffer (zero it first).
+    # Minimum number of 256x256 output tiles for which one grouped wgrad launch beats the per-GEMM split-K launches
+    # (measured on C3: 1944 tiles 3.25 -> 2.01 ms, 384 tiles 1.92 -> 1.86 ms, 324 tiles 0.81 -> 0.91 ms; 256 CUs).
+    WGRAD_MIN_TILES = 512
 
-        Three launch segments (decoder side, joint encoder, encoder/embedding side); after each one the gradient
-        slices it completed are handed to ``grad_hook`` (bucketed RCCL all-reduce overlapping the next segment).
+    def _wgrad_plan(self) -> str:
+        """"fused" | "all" (every stack deferred into ONE launch at the end of the backward; only without a gradient hook,
+        because every weight gradient then completes last) | "enc" (data parallel: the group encoders' chunks are
+        deferred per segment, so finished slices still overlap the all-reduce; joint / decoder stay fused)."""
+        if self.wgrad_mode == "fused":
+            return "fused"
+        hooked = self.grad_hook is not None
+        plan = self._wgrad_plans.get((self.wgrad_mode, hooked))
+        if plan is not None:
+            return plan
+        stacks = list(self.enc.values()) if hooked else self._all_stacks()
+        try:
+            tiles = [hip.GroupedTN.count_tiles(st.wgrad_problems()) for st in stacks]
+            ok = True
+        except hip.HipExtensionError:
+            tiles, ok = [], False
+        if not ok:
+            if self.wgrad_mode == "deferred":
+                raise hip.HipExtensionError("MAESTRO_WGRAD=deferred: a weight-gradient problem is not eligible for the grouped GEMM")
+            plan = "fused"
+        elif hooked:
+            n_seg = len(self._enc_cuts()) - 1
+            plan = "enc" if self.wgrad_mode == "deferred" or sum(tiles) // n_seg >= self.WGRAD_MIN_TILES else "fused"
+        else:
+            plan = "all" if self.wgrad_mode == "deferred" or sum(tiles) >= self.WGRAD_MIN_TILES else "fused"
+        self._wgrad_plans[(self.wgrad_mode, hooked)] = plan
+        return plan
+
+    def _all_stacks(self) -> list:
+        return list(self.dec.values()) + ([self.joint] if self.joint is not None else []) + list(self.enc.values())
+
+    def _launch_wgrads(self, items) -> None:
+        """One grouped launch for the deferred weight gradients of ``items`` = [(stack, lo, hi)]; the descriptor table is
+        built on first use (always an eager run: segments are captured on their second run)."""
+        items = [(st, lo, hi) for st, lo, hi in items if hi > lo]
+        if not items:
+            return
+        key = tuple((st.tag, lo, hi) for st, lo, hi in items)
+        table = self._wgrad_tables.get(key)
+        if table is None:
+            probs = [p for st, lo, hi in items for p in st.wgrad_problems(lo, hi)]
+            table = self._wgrad_tables[key] = hip.GroupedTN(probs, self.device)
+        table.launch()
+
+    def _enc_cuts(self) -> list:
+        # encoder side: with a gradient hook (data parallel) cut it into layer ranges so the all-reduce of the finished
+        # slices overlaps the remaining layers (~85 % of the parameters live in the group encoders)
+        depth = max(st.depth for st in self.enc.values())
+        return [depth, 0] if self.grad_hook is None or depth < 3 else [depth, depth - depth // 3, depth // 3, 0]
+
+    def backward(self, grad_scale: float = 1.0) -> None:
+        """Backward of the last ``forward`` (d loss = 1) into the flat grad buffer, which must have been zeroed for this
+        step (bias / norm gradients accumulate atomically; deferred weight gradients are stored, not added).
+
+        Launch segments: decoder side, joint encoder, encoder/embedding side (cut in three with a gradient hook); after
+        each one the gradient slices it completed are handed to ``grad_hook`` (bucketed RCCL all-reduce overlapping the
+        next segment).
         """
         if grad_scale != 1.0:
             raise NotImplementedError("loss scaling is not needed for bf16 (SURVEY §8(f) AMP row)")
         key = getattr(self, "_cur_key", None)
-        self._segment("bwd_dec", key, self._bwd_decoder_side)
+        plan = self._plan = self._wgrad_plan()
+        sfx = f":{plan}:{'h' if self.grad_hook is not None else 'n'}"   # graphs are specific to the launch plan
+        self._segment("bwd_dec" + sfx, key, self._bwd_decoder_side)
         if self.joint is not None:
-            self._segment("bwd_joint", key, self._bwd_joint)
-        # encoder side: with a gradient hook (data parallel) cut it into layer ranges so the all-reduce of the finished
-        # slices overlaps the remaining layers (~85 % of the parameters live in the group encoders)
-        depth = max(st.depth for st in self.enc.values())
-        cuts = [depth, 0] if self.grad_hook is None or depth < 3 else [depth, depth - depth // 3, depth // 3, 0]
+            self._segment("bwd_joint" + sfx, key, self._bwd_joint)
+        cuts = self._enc_cuts()
         for i in range(len(cuts) - 1):
-            self._segment(f"bwd_enc{i}", key, lambda hi=cuts[i], lo=cuts[i + 1], first=(i == 0), last=(i == len(cuts) - 2):
+            self._segment(f"bwd_enc{i}" + sfx, key, lambda hi=cuts[i], lo=cuts[i + 1], first=(i == 0), last=(i == len(cuts) - 2):
                           self._bwd_encoder_side(hi, lo, first, last))
 
     def _bwd_decoder_side(self) -> None:
@@ -576,7 +616,7 @@ class MAEEngine:
             def run():
                 gbuf, st = self.gb[g.name], self.dec[g.name]
                 nrm = st.t.norm
-                dx, dx16 = st.dxa, st.dxa16          # gradient w.r.t. the decoder's last residual
+                dx, dx16 = st.dxa, st.top16          # gradient w.r.t. the decoder's last residual
                 for s in g.mods:
                     b = self.mb[s.name]
                     T = s.Beff * s.n_tok  # noqa: N806
@@ -589,7 +629,7 @@ class MAEEngine:
                                       None, dx, dx16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(), gbuf["ln_ws"],
                                       s.Beff, s.n_tok, Dd)
                     self._grads_ready(m.embed_to_rec[s.embed])
-                dx0, _ = st.backward(dx, dx16)
+                dx0, _ = st.backward(dx, defer=self._plan == "all")
                 self._grads_ready(nrm)
                 # unmask backward: visible rows -> enc_to_dec output grad; masked rows -> mask-token grads
                 hip.gather_rows(dx0, gbuf["vis"], gbuf["dy_e2d"], g.Beff, g.L, g.N, Dd, g.N, 0)
@@ -608,7 +648,7 @@ class MAEEngine:
                     jt = self.joint
                     jn = jt.t.norm
                     hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, jt.x_last, m.joint_N, g.joint_off, jn.weight, gbuf["mean_j"],
-                                      gbuf["rstd_j"], None, jt.dxa, jt.dxa16, ps.g(jn.weight), ps.g(jn.bias),
+                                      gbuf["rstd_j"], None, jt.dxa, jt.top16, ps.g(jn.weight), ps.g(jn.bias),
                                       jt.top_bias_grad(), gbuf["ln_ws"], g.Beff, g.N, E)
             return run
 
@@ -616,7 +656,7 @@ class MAEEngine:
 
     def _bwd_joint(self) -> None:
         jt = self.joint
-        self._djoint, _ = jt.backward(jt.dxa, jt.dxa16)
+        self._djoint, _ = jt.backward(jt.dxa, defer=self._plan == "all")
         self._grads_ready(jt.t.norm)
 
     def _bwd_encoder_side(self, hi: int, lo: int, first: bool, last: bool) -> None:
@@ -633,16 +673,16 @@ class MAEEngine:
                 if first:
                     if self.joint is not None:
                         hip.layernorm_bwd(self._djoint, m.joint_N, g.joint_off, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"],
-                                          gbuf["rstd_e"], None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias),
+                                          gbuf["rstd_e"], None, st.dxa, st.top16, ps.g(nrm.weight), ps.g(nrm.bias),
                                           st.top_bias_grad(), gbuf["ln_ws"], g.Beff, g.N, E)
                     else:
                         hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"],
-                                          gbuf["rstd_e"], None, st.dxa, st.dxa16, ps.g(nrm.weight), ps.g(nrm.bias),
+                                          gbuf["rstd_e"], None, st.dxa, st.top16, ps.g(nrm.weight), ps.g(nrm.bias),
                                           st.top_bias_grad(), gbuf["ln_ws"], g.Beff, g.N, E)
                     self._grads_ready(nrm)
-                    self._enc_state[g.name] = (st.dxa, st.dxa16)
-                cur, cur16 = self._enc_state[g.name]
-                self._enc_state[g.name] = st.backward(cur, cur16, s_hi, s_lo)
+                    self._enc_state[g.name] = (st.dxa, st.top16)
+                cur, _ = self._enc_state[g.name]
+                self._enc_state[g.name] = st.backward(cur, s_hi, s_lo, defer=self._plan != "fused")
                 if not last:
                     return
                 dx0 = self._enc_state[g.name][0]
@@ -663,6 +703,10 @@ class MAEEngine:
             return run
 
         self._run_parallel([side(g) for g in self.groups])
+        if self._plan == "enc":      # this segment's layers of every group encoder
+            self._launch_wgrads([(st, min(lo, st.depth), min(hi, st.depth)) for st in self.enc.values()])
+        elif self._plan == "all" and last:
+            self._launch_wgrads([(st, 0, st.depth) for st in self._all_stacks()])
         if last:
             for name in m.patch_embed:
                 self._grads_ready(m.patch_embed[name])

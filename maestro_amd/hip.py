@@ -305,24 +305,45 @@ def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):  # noqa: F811
 class _MhGroupedGemm(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("M", ctypes.c_int),
                 ("N", ctypes.c_int), ("K", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int),
-                ("tile_begin", ctypes.c_int), ("reserved", ctypes.c_int)]
+                ("tile_begin", ctypes.c_int), ("accumulate", ctypes.c_int)]
 
 
 class GroupedTN:
     """Descriptor table (built once: all buffers are static) for ``mh_gemm_grouped_tn``: every entry is one
-    dW[M, N] (f32, plain store) = A[K, M]^T B[K, N] problem; the launch covers all their 256x256 tiles."""
+    dW[M, N] (f32) = A[K, M]^T B[K, N] problem; the launch covers all their 256x256 tiles.  A dW written by a single
+    problem is stored; one shared by several problems (same encoder on several groups) is accumulated atomically."""
+
+    @staticmethod
+    def check(i, prob) -> int:
+        """Validates one problem against the kernel's addressing limits; returns its number of 256x256 tiles."""
+        A, B, C, M, N, K, lda, ldb, ldc = prob  # noqa: N806
+        if M % 8 or N % 8 or lda % 8 or ldb % 8 or ldc % 4 or min(M, N, K) <= 0:
+            raise HipExtensionError(f"grouped wgrad problem {i}: M, N, lda, ldb must be multiples of 8 ({M}, {N}, {lda}, {ldb})")
+        if C.dtype != torch.float32 or A.dtype != torch.bfloat16 or B.dtype != torch.bfloat16:
+            raise HipExtensionError("grouped wgrad: A, B bf16 and C f32 expected")
+        if (-(-K // 32) * 32) * max(lda, ldb) * 2 + 65536 >= 1 << 31:
+            raise HipExtensionError(f"grouped wgrad problem {i}: operand beyond the 2 GiB buffer-descriptor range")
+        return -(-M // 256) * -(-N // 256)
+
+    @staticmethod
+    def count_tiles(problems) -> int:
+        return sum(GroupedTN.check(i, p) for i, p in enumerate(problems))
 
     def __init__(self, problems, device) -> None:
+        # longest-first: workgroups are dispatched in tile order and a tile's duration is proportional to its K
+        problems = sorted(problems, key=lambda p: -p[5])
         arr = (_MhGroupedGemm * len(problems))()
         tiles = 0
         self.keep = []
-        for i, (A, B, C, M, N, K, lda, ldb, ldc) in enumerate(problems):
-            if M % 8 or N % 8 or lda % 8 or ldb % 8 or ldc % 4:
-                raise HipExtensionError(f"grouped wgrad problem {i}: M, N, lda, ldb must be multiples of 8 ({M}, {N}, {lda}, {ldb})")
-            if C.dtype != torch.float32 or A.dtype != torch.bfloat16 or B.dtype != torch.bfloat16:
-                raise HipExtensionError("grouped wgrad: A, B bf16 and C f32 expected")
-            arr[i] = _MhGroupedGemm(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, lda, ldb, ldc, tiles, 0)
-            tiles += -(-M // 256) * -(-N // 256)
+        writers = {}
+        for prob in problems:
+            writers[prob[2].data_ptr()] = writers.get(prob[2].data_ptr(), 0) + 1
+        for i, prob in enumerate(problems):
+            A, B, C, M, N, K, lda, ldb, ldc = prob  # noqa: N806
+            n = self.check(i, prob)
+            shared = int(writers[C.data_ptr()] > 1)   # several problems add into one (zeroed) dW: atomic epilogue
+            arr[i] = _MhGroupedGemm(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, lda, ldb, ldc, tiles, shared)
+            tiles += n
             self.keep += [A, B, C]
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.table = raw.to(device)

@@ -86,3 +86,22 @@ def test_grouped_tn_exact_and_timed():
     torch.cuda.synchronize()
     for (A, B, C, *_), want in zip(probs, wants):
         assert torch.equal(C, want), (C - want).abs().max().item()
+
+
+def test_grouped_tn_shared_output_accumulates():
+    """Several problems writing one dW (an encoder shared by several groups) add up atomically; others are stored."""
+    from maestro_amd import hip
+    dev = _dev()
+    M, N = 264, 520
+    shared = torch.zeros(M, N, device=dev)
+    probs, want_shared = [], torch.zeros(M, N, device=dev)
+    for K in (300, 77, 1024):
+        A, B, want = _operands(2, M, N, K, dev, integer=True)
+        probs.append((A, B, shared, M, N, K, M, N, N))
+        want_shared += want
+    A, B, want_own = _operands(2, 512, 256, 200, dev, integer=True)
+    own = torch.full((512, 256), float("nan"), device=dev)
+    probs.append((A, B, own, 512, 256, 200, 512, 256, 256))
+    hip.GroupedTN(probs, dev).launch()
+    torch.cuda.synchronize()
+    assert torch.equal(shared, want_shared) and torch.equal(own, want_own)

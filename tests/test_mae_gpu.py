@@ -48,10 +48,13 @@ def _setup(name, golden_dir):
     return dev, case, gold, ds, oracle, model, batch, noise, struct
 
 
+@pytest.mark.parametrize("wgrad", ["fused", "deferred"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_engine_matches_oracle_and_reference(golden_dir, name):
+def test_engine_matches_oracle_and_reference(golden_dir, name, wgrad):
+    """``wgrad``: weight gradients in line with the dgrad chain (split-K atomics) / deferred into one grouped launch."""
     dev, case, gold, ds, oracle, model, batch, noise, struct = _setup(name, golden_dir)
     eng = model.engine(case["B"], dev, loss="l2_norm")
+    eng.wgrad_mode = wgrad
     dbatch = {k: v.to(dev) for k, v in batch.items()}
     loss = eng.forward(dbatch, noise=noise, struct=struct)
     eng.zero_grad()
@@ -138,17 +141,19 @@ def test_forward_api_and_seeded_rng(golden_dir):
     assert torch.equal(dbatch["dem"].cpu(), batch["dem"])  # caller's tensor is left untouched
 
 
-def test_graph_replay_and_streams_match_eager(golden_dir):
+@pytest.mark.parametrize("wgrad", ["fused", "deferred"])
+def test_graph_replay_and_streams_match_eager(golden_dir, wgrad):
     """Steps 2+ replay captured hipGraphs with group-parallel streams; results must match the eager single-stream run."""
     dev, case, gold, ds, oracle, model, batch, noise, struct = _setup("c4_treesat", golden_dir)
     dbatch = {k: v.to(dev) for k, v in batch.items()}
     eng = model.engine(case["B"], dev, loss="l2_norm")
+    eng.wgrad_mode = "fused"
     eng.use_graphs, eng.multi_stream = False, False
     ref_loss = eng.forward(dbatch, noise=noise, struct=struct).item()
     eng.zero_grad()
     eng.backward()
     ref_grad = eng.store.grad.clone()
-    eng.use_graphs, eng.multi_stream = True, True
+    eng.use_graphs, eng.multi_stream, eng.wgrad_mode = True, True, wgrad
     for it in range(4):   # eager+streams, capture, replay, replay
         loss = eng.forward(dbatch, noise=noise, struct=struct).item()
         eng.zero_grad()
@@ -157,7 +162,8 @@ def test_graph_replay_and_streams_match_eager(golden_dir):
         assert abs(loss - ref_loss) < 1e-5 * abs(ref_loss), (it, loss, ref_loss)
         rel = ((eng.store.grad - ref_grad).norm() / ref_grad.norm()).item()
         assert rel < 1e-4, (it, rel)
-    assert set(eng._graphs) >= {"forward", "bwd_dec", "bwd_joint", "bwd_enc0"}
+    plan = "fused" if wgrad == "fused" else "all"
+    assert set(eng._graphs) >= {"forward"} | {f"{seg}:{plan}:n" for seg in ("bwd_dec", "bwd_joint", "bwd_enc0")}
 
 
 @pytest.mark.parametrize("interpolate", ["nearest", "bilinear"])
@@ -177,7 +183,8 @@ def test_input_resize_staging_matches_oracle(golden_dir, interpolate):
     assert (returned["aerial"].cpu() - ob["aerial"]).abs().max() < 2e-6 and returned["aerial"].shape[-1] == 64
 
 
-def test_segmented_backward_with_grad_hook_matches_unsegmented():
+@pytest.mark.parametrize("wgrad", ["fused", "deferred"])
+def test_segmented_backward_with_grad_hook_matches_unsegmented(wgrad):
     """With a gradient hook (data parallel) the encoder-side backward is cut into layer ranges; gradients must not change,
     and the reported slices must tile the trainable flat buffer exactly once."""
     if not torch.cuda.is_available():
@@ -195,14 +202,14 @@ def test_segmented_backward_with_grad_hook_matches_unsegmented():
     batch = synthetic_batch(ds.dataset, B, dev)
     torch.manual_seed(5)
     noise, struct = eng.draw_masks()
-    eng.use_graphs = False
+    eng.use_graphs, eng.wgrad_mode = False, "fused"
     eng.forward(batch, noise=noise, struct=struct)
     eng.zero_grad()
     eng.backward()
     ref = eng.store.grad.clone()
     spans = []
     eng.grad_hook = lambda lo, hi: spans.append((lo, hi))
-    eng.use_graphs = True
+    eng.use_graphs, eng.wgrad_mode = True, wgrad
     for it in range(3):
         spans.clear()
         eng.forward(batch, noise=noise, struct=struct)
@@ -214,7 +221,8 @@ def test_segmented_backward_with_grad_hook_matches_unsegmented():
         covered = sorted(set(spans))
         assert covered[0][0] == 0 and covered[-1][1] == eng.store.total
         assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), "reported gradient slices overlap or leave gaps"
-    assert {"bwd_enc0", "bwd_enc1", "bwd_enc2"} <= set(eng._graphs)
+    plan = "fused" if wgrad == "fused" else "enc"
+    assert {f"bwd_enc{i}:{plan}:h" for i in range(3)} <= set(eng._graphs)
 
 
 def test_ssl_module_lightning_style_step(golden_dir):
