@@ -45,12 +45,18 @@ int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const 
                  int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                  int ldaux, void* stream);
 
-/* Same contract through the large-tile LDS-DMA kernel (256x256x32 tile, 4-stage LDS ring; gemm_dma.hip).  Returns -2
- * when the problem does not qualify (K tail inside a K-minor operand, > 2 GiB operands): call mh_gemm_bf16 instead.
- * mh_gemm_bf16 itself dispatches here for the shapes where this kernel is faster. */
-int mh_gemm_bf16_dma(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                     int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
-                     int ldaux, void* stream);
+/* Same contract with an explicit kernel / tile choice (what mh_gemm_bf16 picks by itself with MH_TILE_AUTO):
+ *   MH_TILE_REG_128      128x128x64 tile, register-staged double-buffered LDS (gemm.hip): every shape / tail
+ *   MH_TILE_DMA_256      256x256x32 tile, 8 waves, 4-stage LDS-DMA ring (gemm_dma.hip)
+ *   MH_TILE_DMA_256x128 / MH_TILE_DMA_128x256   4 waves, 3-stage ring;   MH_TILE_DMA_128   128x128, 2 waves, 4-stage ring
+ * The DMA tiles return -2 (nothing launched, error string untouched) when the problem does not qualify (K %% 32 != 0 with
+ * a K-minor operand, operands beyond the 2 GiB buffer-descriptor range): pick another tile.  The host side times the
+ * eligible tiles once per distinct (layout, M, N, K, flags) and remembers the fastest (maestro_amd/hip.py). */
+enum { MH_TILE_AUTO = -1, MH_TILE_REG_128 = 0, MH_TILE_DMA_256 = 1, MH_TILE_DMA_256x128 = 2, MH_TILE_DMA_128x256 = 3,
+       MH_TILE_DMA_128 = 4 };
+int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                      int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
+                      int ldaux, void* stream);
 
 /* Grouped weight-gradient GEMM: ONE launch over the 256x256 tiles of many independent "TN" problems
  * dW_i[M_i, N_i] (f32) = A_i^T B_i with A_i [K_i, M_i] bf16 (= dY_i), B_i [K_i, N_i] bf16 (= X_i), K_i = tokens.

@@ -260,9 +260,10 @@ static bool prefer_dma(int layout, int M, int N, int K, int flags) {
     return 10 * tiles >= 9 * 256 * waves;
 }
 
-extern "C" int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
-                            int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in,
-                            void* aux_out, int ldaux, void* stream) {
+extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                                 void* C, int ldc, int flags, const float* bias, const float* res, int ldr,
+                                 const void* aux_in, void* aux_out, int ldaux, void* stream) {
+    MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_DMA_128, "mh_gemm_bf16: tile %d", tile);
     MH_CHECK_ARG(layout >= 0 && layout <= 2, "mh_gemm_bf16: layout %d", layout);
     MH_CHECK_ARG(M > 0 && N > 0 && K > 0, "mh_gemm_bf16: empty problem %d %d %d", M, N, K);
     MH_CHECK_ARG(A && B && C, "mh_gemm_bf16: null operand");
@@ -286,9 +287,11 @@ extern "C" int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int 
     MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || !(flags & ~(MH_GEMM_ATOMIC | MH_GEMM_OUT_F32)),
                  "mh_gemm_bf16: atomic accumulate excludes other epilogues");
 
-    if (prefer_dma(layout, M, N, K, flags)) {
-        const int rc = mh_gemm_bf16_dma(layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux,
-                                        stream);
+    if (tile > MH_TILE_REG_128)   // explicit DMA tile: -2 when not eligible (the caller picks another tile)
+        return gemm_dma_dispatch(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, stream);
+    if (tile == MH_TILE_AUTO && prefer_dma(layout, M, N, K, flags)) {
+        const int rc = gemm_dma_dispatch(MH_TILE_DMA_256, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in,
+                                         aux_out, ldaux, stream);
         if (rc != -2) return rc;   // -2: not eligible -> general kernel below
     }
     GemmParams p;
@@ -325,4 +328,11 @@ extern "C" int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int 
     }
     MH_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                            int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in,
+                            void* aux_out, int ldaux, void* stream) {
+    return mh_gemm_bf16_tile(MH_TILE_AUTO, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out,
+                             ldaux, stream);
 }

@@ -14,6 +14,10 @@ struct GemmParams {
     unsigned a_bytes, b_bytes;
 };
 
+// gemm_dma.hip: the LDS-DMA tile family (tile = MH_TILE_DMA_*); -2 = not eligible, nothing launched
+int gemm_dma_dispatch(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                      int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
+                      int ldaux, void* stream);
 
 // Row-major epilogue: each wave transposes its tile through a private LDS region (passes of 32 rows, 68-float row pitch:
 // conflict-free ds_write_b128 / ds_read_b128) so that the bias / residual / aux reads and the C / aux writes are done in

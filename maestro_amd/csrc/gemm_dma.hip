@@ -18,9 +18,22 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 32, NT = 512, STAGES = 4;
-constexpr int OPER_BYTES = 256 * 32 * 2;       // one operand tile of one stage: 16 KiB
-constexpr int STAGE_BYTES = 2 * OPER_BYTES;    // A + B
+constexpr int BK = 32;
+
+// Tile configuration: WM x WN waves, each owning a 128 (M) x 64 (N) accumulator block; S ring stages.
+//   <2,4,4> 256x256, 512 threads, 128 KiB ring (1 workgroup / CU)      <2,2,3> 256x128 and <1,4,3> 128x256, 256 threads,
+//   72 KiB ring (2 / CU)      <1,2,4> 128x128, 128 threads, 64 KiB ring (2 / CU)
+template <int WM_, int WN_, int S_>
+struct Tile {
+    static constexpr int WM = WM_, WN = WN_, S = S_;
+    static constexpr int BM = 128 * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;   // 1-KiB DMA pieces per wave and K step
+    static constexpr int LDS_BYTES = S * STAGE_BYTES;
+    static_assert(BN >= 128, "the K-major swizzle needs at least 8 32-byte chunks per row");
+    static_assert(PA * NW * 1024 == A_BYTES && PB * NW * 1024 == B_BYTES, "pieces must divide evenly over the waves");
+    static_assert(LDS_BYTES >= NW * 32 * 68 * 4, "the ring doubles as epilogue staging");
+};
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((address_space(3))) void lds_void;
@@ -28,17 +41,19 @@ typedef __attribute__((address_space(3))) void lds_void;
 __device__ __forceinline__ int kminor_sw(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
 __device__ __forceinline__ int kmajor_sw(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
-// Per-lane source byte offsets (relative to the operand base at k = 0) of the two DMA pieces a wave issues per K step.
-template <bool KMAJOR>
-__device__ __forceinline__ void piece_offsets(int ld, int rc0, int w, int l, int (&voff)[2]) {
+// Per-lane source byte offsets (relative to the operand base at k = 0) of the NP DMA pieces a wave issues per K step for
+// an operand tile of BX rows / columns (NW waves share its BX / 16 pieces).
+template <bool KMAJOR, int BX, int NW, int NP>
+__device__ __forceinline__ void piece_offsets(int ld, int rc0, int w, int l, int (&voff)[NP]) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int piece = w + 8 * h;                       // 16 pieces per operand tile
+    for (int h = 0; h < NP; ++h) {
+        const int piece = w + NW * h;
         if constexpr (!KMAJOR) {                           // piece = 16 rows x 64 B
             const int row = piece * 16 + (l >> 2), pos = l & 3;
             voff[h] = ((rc0 + row) * ld + ((pos ^ kminor_sw(row)) << 3)) * 2;
-        } else {                                           // piece = 2 k-rows x 512 B
-            const int k = piece * 2 + (l >> 5), s16 = l & 31;
+        } else {                                           // piece = (512 / BX) k-rows x (2 BX) B
+            constexpr int LPR = BX / 8;                    // lanes (16-byte chunks) per k-row
+            const int k = piece * (64 / LPR) + l / LPR, s16 = l % LPR;
             const int q = (s16 >> 1) ^ kmajor_sw(k);
             voff[h] = (k * ld + rc0 + (((q << 1) | (s16 & 1)) << 3)) * 2;
         }
@@ -46,53 +61,61 @@ __device__ __forceinline__ void piece_offsets(int ld, int rc0, int w, int l, int
 }
 
 // fragment of rows/cols (rc0 + lane&15) of a stage's operand image: 8 bf16 along k = 8*(lane>>4) + j
-template <bool KMAJOR>
+template <bool KMAJOR, int BX>
 __device__ __forceinline__ bf16x8 read_frag(const unsigned char* img, int rc0) {
     const int l = threadIdx.x & 63;
     if constexpr (!KMAJOR) {
         const int row = rc0 + (l & 15), g = l >> 4;
         return *reinterpret_cast<const bf16x8*>(img + row * 64 + ((g ^ kminor_sw(row)) << 4));
     } else {
+        constexpr int ROWB = BX * 2;
         const int g = l >> 4, qrow = (l & 15) >> 2, p = l & 3, q = rc0 >> 4;
         const int k_lo = 8 * g + qrow, k_hi = k_lo + 4;
         const lds_u8* base = (const lds_u8*)img;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(base + k_lo * 512 + (((q ^ kmajor_sw(k_lo)) << 5) + p * 8)));
+            (__attribute__((address_space(3))) s16x4*)(base + k_lo * ROWB + (((q ^ kmajor_sw(k_lo)) << 5) + p * 8)));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(base + k_hi * 512 + (((q ^ kmajor_sw(k_hi)) << 5) + p * 8)));
+            (__attribute__((address_space(3))) s16x4*)(base + k_hi * ROWB + (((q ^ kmajor_sw(k_hi)) << 5) + p * 8)));
         s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, r);
     }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// (CALLER only makes the instantiations of the two kernels distinct: the host pass of hipcc 7.2 rejects the second request
+// for one and the same specialization with a bogus "substitution failure".)
+template <class T, bool A_KMAJOR, bool B_KMAJOR, int CALLER>
 __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, int tile_n, int kbeg, int kend,
                                               unsigned char* smem) {
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    constexpr int S = T::S, PA = T::PA, PB = T::PB, NW = T::NW;
+    const int m0 = tile_m * T::BM, n0 = tile_n * T::BN;
     const int nk = (kend - kbeg + BK - 1) / BK;
 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
-    const int wm = (w >> 2) * 128, wn = (w & 3) * 64;
+    const int wm = (w / T::WN) * 128, wn = (w % T::WN) * 64;
 
     const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, (short)0, (int)p.b_bytes, 0x00020000);
-    int va[2], vb[2];
-    piece_offsets<A_KMAJOR>(p.lda, m0, w, l, va);
-    piece_offsets<B_KMAJOR>(p.ldb, n0, w, l, vb);
+    int va[PA], vb[PB];
+    piece_offsets<A_KMAJOR, T::BM, NW, PA>(p.lda, m0, w, l, va);
+    piece_offsets<B_KMAJOR, T::BN, NW, PB>(p.ldb, n0, w, l, vb);
     const int a_step = A_KMAJOR ? BK * p.lda * 2 : BK * 2;   // source bytes per K step
     const int b_step = B_KMAJOR ? BK * p.ldb * 2 : BK * 2;
     const int a_off0 = A_KMAJOR ? kbeg * p.lda * 2 : kbeg * 2;
     const int b_off0 = B_KMAJOR ? kbeg * p.ldb * 2 : kbeg * 2;
 
-    auto issue = [&](int t) {  // DMA the operand tiles of K step t into ring slot t % STAGES (4 pieces per wave)
-        unsigned char* slot = smem + (t & (STAGES - 1)) * STAGE_BYTES;
+    auto issue = [&](int t) {  // DMA the operand tiles of K step t into ring slot t % S (PA + PB pieces per wave)
+        unsigned char* slot = smem + (t % S) * T::STAGE_BYTES;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_src, (lds_void*)(slot + (w + 8 * h) * 1024), 16, va[h],
+        for (int h = 0; h < PA; ++h)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_src, (lds_void*)(slot + (w + NW * h) * 1024), 16, va[h],
                                                      a_off0 + t * a_step, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_src, (lds_void*)(slot + OPER_BYTES + (w + 8 * h) * 1024), 16, vb[h],
+#pragma unroll
+        for (int h = 0; h < PB; ++h)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_src, (lds_void*)(slot + T::A_BYTES + (w + NW * h) * 1024), 16, vb[h],
                                                      b_off0 + t * b_step, 0, 0);
-        }
     };
 
     f32x4 acc[4][8];  // [j (n tile)][i (m tile)]
@@ -101,22 +124,23 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int t = 0; t < STAGES - 1 && t < nk; ++t) issue(t);
+    for (int t = 0; t < S - 1 && t < nk; ++t) issue(t);
 
     for (int t = 0; t < nk; ++t) {
-        // my pieces of step t have landed once at most the two younger steps (8 / 4 / 0 DMA instructions) are pending
-        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // my pieces of step t have landed once at most the S - 2 younger steps' DMA instructions are still pending
+        const int younger = min(S - 2, nk - 1 - t);
+        if (younger >= 2) wait_vmcnt<2 * (PA + PB)>();
+        else if (younger == 1) wait_vmcnt<PA + PB>();
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();   // everybody's pieces of step t are in LDS; step t-1 has been read by everybody
-        if (t + STAGES - 1 < nk) issue(t + STAGES - 1);   // refill the slot step t-1 just vacated
-        const unsigned char* ta = smem + (t & (STAGES - 1)) * STAGE_BYTES;
-        const unsigned char* tb = ta + OPER_BYTES;
+        if (t + S - 1 < nk) issue(t + S - 1);   // refill the slot step t-1 just vacated
+        const unsigned char* ta = smem + (t % S) * T::STAGE_BYTES;
+        const unsigned char* tb = ta + T::A_BYTES;
         bf16x8 fa[8], fb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR>(tb, wn + 16 * j);
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR, T::BN>(tb, wn + 16 * j);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = read_frag<A_KMAJOR>(ta, wm + 16 * i);
+        for (int i = 0; i < 8; ++i) fa[i] = read_frag<A_KMAJOR, T::BM>(ta, wm + 16 * i);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -130,9 +154,9 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
     else gemm_epilogue_store<8>(p, acc, st, m0 + wm, n0 + wn);
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(NT, 2) void gemm_dma_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE_BYTES];  // 128 KiB: the ONLY LDS object
+template <class T, bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(T::NT) void gemm_dma_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[T::LDS_BYTES];  // the ONLY LDS object
     const int nwg = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nwg);
     constexpr int GROUP_M = 4;
@@ -142,14 +166,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_dma_kernel(GemmParams p) {
     const int gsz = min(p.tiles_m - first_m, GROUP_M);
     const int tile_m = first_m + in_group % gsz, tile_n = in_group / gsz;
     const int kbeg = blockIdx.y * p.k_per_split;
-    gemm_dma_tile<A_KMAJOR, B_KMAJOR>(p, tile_m, tile_n, kbeg, min(p.K, kbeg + p.k_per_split), smem);
+    gemm_dma_tile<T, A_KMAJOR, B_KMAJOR, 0>(p, tile_m, tile_n, kbeg, min(p.K, kbeg + p.k_per_split), smem);
 }
 
+typedef Tile<2, 4, 4> T256;      // 256 x 256
+typedef Tile<2, 2, 3> T256x128;  // 256 x 128
+typedef Tile<1, 4, 3> T128x256;  // 128 x 256
+typedef Tile<1, 2, 4> T128;      // 128 x 128
+
 // Grouped weight-gradient launch: ONE grid over the 256x256 tiles of many independent TN problems
-// (dW_i[M_i, N_i] = dY_i^T X_i, K_i = tokens), no split-K, plain fp32 stores.  Workgroup b finds its problem by a scalar
-// scan of the tile prefix (a few dozen entries) and runs the same tile routine.
-__global__ __launch_bounds__(NT, 2) void gemm_dma_grouped_tn_kernel(const MhGroupedGemm* __restrict__ table, int n_problems) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE_BYTES];
+// (dW_i[M_i, N_i] = dY_i^T X_i, K_i = tokens), no split-K.  Workgroup b finds its problem by a scalar scan of the tile
+// prefix (a few dozen entries) and runs the same tile routine.
+template <class T>
+__global__ __launch_bounds__(T::NT) void gemm_dma_grouped_tn_kernel(const MhGroupedGemm* __restrict__ table, int n_problems) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[T::LDS_BYTES];
     const int b = blockIdx.x;
     int i = 0;
     while (i + 1 < n_problems && table[i + 1].tile_begin <= b) ++i;   // uniform: scalar loads
@@ -159,28 +189,53 @@ __global__ __launch_bounds__(NT, 2) void gemm_dma_grouped_tn_kernel(const MhGrou
     p.bias = nullptr; p.res = nullptr; p.aux_in = nullptr; p.aux_out = nullptr;
     p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.ldr = 0; p.ldaux = 0;
     p.flags = MH_GEMM_OUT_F32 | (g.accumulate ? MH_GEMM_ATOMIC : 0);
-    p.tiles_m = (g.M + BM - 1) / BM; p.tiles_n = (g.N + BN - 1) / BN; p.k_per_split = g.K; p.fast = 1;
+    p.tiles_m = (g.M + T::BM - 1) / T::BM; p.tiles_n = (g.N + T::BN - 1) / T::BN; p.k_per_split = g.K; p.fast = 1;
     p.a_bytes = (unsigned)(((long)(g.K - 1) * g.lda + g.M) * 2);
     p.b_bytes = (unsigned)(((long)(g.K - 1) * g.ldb + g.N) * 2);
     const int t = b - g.tile_begin;                     // consecutive workgroups share the A panel (same tile_m)
-    gemm_dma_tile<true, true>(p, t / p.tiles_n, t % p.tiles_n, 0, g.K, smem);
+    gemm_dma_tile<T, true, true, 1>(p, t / p.tiles_n, t % p.tiles_n, 0, g.K, smem);
+}
+
+template <class T>
+int launch_dma(int layout, GemmParams& p, hipStream_t s) {
+    const int M = p.M, N = p.N, K = p.K;
+    const bool a_kmajor = layout == 2, b_kmajor = layout != 0;
+    p.tiles_m = ceil_div(M, T::BM); p.tiles_n = ceil_div(N, T::BN);
+    const long a_reach = a_kmajor ? (long)(ceil_div(K, BK) * BK) * p.lda * 2 : (long)(p.tiles_m * T::BM) * p.lda * 2;
+    const long b_reach = b_kmajor ? (long)(ceil_div(K, BK) * BK) * p.ldb * 2 : (long)(p.tiles_n * T::BN) * p.ldb * 2;
+    if (a_reach + 65536 >= (1L << 31) || b_reach + 65536 >= (1L << 31)) return -2;
+    int splits = 1;
+    if (p.flags & MH_GEMM_ATOMIC) {
+        const int tiles = p.tiles_m * p.tiles_n, ksteps = ceil_div(K, BK);
+        const int slots = 256 * (T::LDS_BYTES > 80 * 1024 ? 1 : 2);
+        splits = max(1, min(min(slots / max(tiles, 1), ksteps / 8), 32));
+    }
+    const int ksteps_per = ceil_div(ceil_div(K, BK), splits);
+    p.k_per_split = ksteps_per * BK;
+    splits = ceil_div(K, p.k_per_split);
+    dim3 grid(p.tiles_m * p.tiles_n, splits), block(T::NT);
+    switch (layout) {
+        case 0: hipLaunchKernelGGL((gemm_dma_kernel<T, false, false>), grid, block, 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_dma_kernel<T, false, true>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_dma_kernel<T, true, true>), grid, block, 0, s, p); break;
+    }
+    return 0;
 }
 
 }  // namespace
 
 extern "C" int mh_gemm_grouped_tn(const MhGroupedGemm* table_device, int n_problems, int total_tiles, void* stream) {
     MH_CHECK_ARG(table_device && n_problems > 0 && total_tiles > 0, "mh_gemm_grouped_tn: bad arguments");
-    hipLaunchKernelGGL(gemm_dma_grouped_tn_kernel, dim3(total_tiles), dim3(NT), 0, (hipStream_t)stream, table_device, n_problems);
+    hipLaunchKernelGGL(gemm_dma_grouped_tn_kernel<T256>, dim3(total_tiles), dim3(T256::NT), 0, (hipStream_t)stream, table_device, n_problems);
     MH_LAUNCH_CHECK();
     return 0;
 }
 
-// Same contract as mh_gemm_bf16 (include/maestro_hip.h) restricted to what the DMA path supports; returns -2 (without
-// touching the error string) when the problem does not qualify so that the caller can use the general kernel.
-extern "C" int mh_gemm_bf16_dma(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
-                                int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in,
-                                void* aux_out, int ldaux, void* stream) {
-    if (layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return -2;
+// Called by mh_gemm_bf16 / mh_gemm_bf16_tile (gemm.hip) after argument validation.  Returns -2 (without touching the
+// error string) when the problem does not qualify for the DMA path, so that the caller can use the general kernel.
+int gemm_dma_dispatch(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                      int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
+                      int ldaux, void* stream) {
     const bool a_kmajor = layout == 2, b_kmajor = layout != 0;
     if ((!a_kmajor || !b_kmajor) && K % BK != 0) return -2;   // a K tail inside a K-minor row would wrap, not read zero
     if (lda % 8 || ldb % 8) return -2;
@@ -188,28 +243,19 @@ extern "C" int mh_gemm_bf16_dma(int layout, int M, int N, int K, const void* A, 
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
     p.bias = bias; p.res = res; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.flags = flags;
-    p.tiles_m = ceil_div(M, BM); p.tiles_n = ceil_div(N, BN);
     const long a_ext = a_kmajor ? ((long)(K - 1) * lda + M) * 2 : ((long)(M - 1) * lda + K) * 2;
     const long b_ext = b_kmajor ? ((long)(K - 1) * ldb + N) * 2 : ((long)(N - 1) * ldb + K) * 2;
-    const long a_reach = a_kmajor ? (long)(ceil_div(K, BK) * BK) * lda * 2 : (long)(p.tiles_m * BM) * lda * 2;
-    const long b_reach = b_kmajor ? (long)(ceil_div(K, BK) * BK) * ldb * 2 : (long)(p.tiles_n * BN) * ldb * 2;
-    if (a_reach + 65536 >= (1L << 31) || b_reach + 65536 >= (1L << 31)) return -2;
     p.fast = 1; p.a_bytes = (unsigned)a_ext; p.b_bytes = (unsigned)b_ext;
-    int splits = 1;
-    if (flags & MH_GEMM_ATOMIC) {
-        const int tiles = p.tiles_m * p.tiles_n, ksteps = ceil_div(K, BK);
-        splits = max(1, min(min(256 / max(tiles, 1), ksteps / 8), 32));
-    }
-    const int ksteps_per = ceil_div(ceil_div(K, BK), splits);
-    p.k_per_split = ksteps_per * BK;
-    splits = ceil_div(K, p.k_per_split);
-    dim3 grid(p.tiles_m * p.tiles_n, splits), block(NT);
     hipStream_t s = (hipStream_t)stream;
-    switch (layout) {
-        case 0: hipLaunchKernelGGL((gemm_dma_kernel<false, false>), grid, block, 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_dma_kernel<false, true>), grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm_dma_kernel<true, true>), grid, block, 0, s, p); break;
+    int rc;
+    switch (tile) {
+        case MH_TILE_DMA_256: rc = launch_dma<T256>(layout, p, s); break;
+        case MH_TILE_DMA_256x128: rc = launch_dma<T256x128>(layout, p, s); break;
+        case MH_TILE_DMA_128x256: rc = launch_dma<T128x256>(layout, p, s); break;
+        case MH_TILE_DMA_128: rc = launch_dma<T128>(layout, p, s); break;
+        default: return -2;
     }
+    if (rc) return rc;
     MH_LAUNCH_CHECK();
     return 0;
 }

@@ -8,6 +8,7 @@ with HIP events on their launch stream for bench.py's roofline leg.
 from __future__ import annotations
 
 import ctypes
+import os
 from pathlib import Path
 
 import torch
@@ -57,18 +58,92 @@ def stream():
 _I, _F, _L = ctypes.c_int, ctypes.c_float, ctypes.c_long
 
 
-def gemm(layout: int, M: int, N: int, K: int, A, lda: int, B, ldb: int, C, ldc: int, flags: int = 0, bias=None,
-         res=None, ldr: int = 0, aux_in=None, aux_out=None, ldaux: int = 0, impl: str = "auto") -> None:
-    if impl == "dma":   # force the large-tile LDS-DMA kernel (tests / micro-benchmarks)
-        rc = lib().mh_gemm_bf16_dma(_I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C), _I(ldc),
-                                    _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux), stream())
+# ---- GEMM: kernel / tile choice (include/maestro_hip.h MH_TILE_*)
+TILE_AUTO, TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128 = -1, 0, 1, 2, 3, 4
+TILES = (TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128)
+_LAYOUT_NAME = {0: "NT", 1: "NN", 2: "TN"}
+_TILE_NAME = {TILE_REG_128: "gemm_kernel<{}>", TILE_DMA_256: "gemm_dma_kernel<256x256,{}>",
+              TILE_DMA_256x128: "gemm_dma_kernel<256x128,{}>", TILE_DMA_128x256: "gemm_dma_kernel<128x256,{}>",
+              TILE_DMA_128: "gemm_dma_kernel<128x128,{}>"}
+_tile_choice: dict = {}     # (layout, M, N, K, flags) -> fastest tile, filled while tuning is on
+_tuning = False
+
+
+def set_gemm_tuning(on: bool) -> None:
+    """While on, the first call of every distinct (layout, M, N, K, flags) times each eligible tile on the call's own
+    operands (device-synchronising: eager launches only, never inside a hipGraph capture) and keeps the fastest."""
+    global _tuning
+    _tuning = bool(on)
+
+
+def gemm_tile_choices() -> dict:
+    return dict(_tile_choice)
+
+
+def _gemm_tile(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux) -> int:  # noqa: N803
+    return lib().mh_gemm_bf16_tile(_I(tile), _I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C),
+                                   _I(ldc), _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux),
+                                   stream())
+
+
+def _tune_gemm(key, args) -> int:
+    best, best_ms = TILE_REG_128, float("inf")
+    for tile in TILES:
+        rc = _gemm_tile(tile, *args)
         if rc == -2:
-            raise HipExtensionError("mh_gemm_bf16_dma: problem does not qualify for the DMA kernel")
-        _check(rc, "mh_gemm_bf16_dma")
-        return
-    _check(lib().mh_gemm_bf16(_I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C), _I(ldc),
-                              _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux),
-                              stream()), "mh_gemm_bf16")
+            continue
+        _check(rc, "mh_gemm_bf16_tile")
+        _gemm_tile(tile, *args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            _gemm_tile(tile, *args)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        if ms < best_ms:
+            best, best_ms = tile, ms
+    _tile_choice[key] = best
+    return best
+
+
+def _pick_tile(layout, M, N, K, flags, args) -> int:  # noqa: N803
+    key = (layout, M, N, K, flags)
+    tile = _tile_choice.get(key)
+    if tile is None:
+        forced = os.environ.get("MH_GEMM_TILE")
+        if forced is not None:
+            return int(forced)
+        # atomically accumulated outputs cannot be re-run for timing: the library's own rule decides
+        tile = _tune_gemm(key, args) if _tuning and not (flags & ATOMIC) else TILE_AUTO
+    return tile
+
+
+def _auto_tile_name(layout, M, N, K, flags) -> int:  # noqa: N803
+    return TILE_DMA_256 if _uses_dma(layout, M, N, K, flags) else TILE_REG_128
+
+
+def gemm(layout: int, M: int, N: int, K: int, A, lda: int, B, ldb: int, C, ldc: int, flags: int = 0, bias=None,  # noqa: N803
+         res=None, ldr: int = 0, aux_in=None, aux_out=None, ldaux: int = 0, tile: int | None = None) -> None:
+    """``tile``: one of TILE_* to force a kernel (tests / micro-benchmarks); default = the tuned choice for this problem
+    signature if there is one, else the library's own rule (MH_TILE_AUTO)."""
+    args = (layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux)
+    explicit = tile is not None
+    if not explicit:
+        tile = _pick_tile(layout, M, N, K, flags, args)
+    ev = None
+    if _timer is not None:
+        named = tile if tile != TILE_AUTO else _auto_tile_name(layout, M, N, K, flags)
+        ev = _timer.record(_TILE_NAME[named].format(_LAYOUT_NAME[layout]), 2.0 * M * N * K, (M, N, K))
+        ev[0].record()
+    rc = _gemm_tile(tile, *args)
+    if rc == -2 and not explicit:      # e.g. MH_GEMM_TILE forced a DMA tile onto a problem with a K tail
+        rc = _gemm_tile(TILE_AUTO, *args)
+    if rc == -2:
+        raise HipExtensionError(f"mh_gemm_bf16_tile: problem ({M}, {N}, {K}) does not qualify for tile {tile}")
+    _check(rc, "mh_gemm_bf16_tile")
+    if ev is not None:
+        ev[1].record()
 
 
 def call(name: str, *args) -> None:
@@ -243,7 +318,6 @@ class KernelTimer:
 
 
 _timer: KernelTimer | None = None
-_GEMM_KERNEL = {GEMM_NT: "gemm_kernel<NT>", GEMM_NN: "gemm_kernel<NN>", GEMM_TN: "gemm_kernel<TN>"}
 
 
 def _uses_dma(layout, M, N, K, flags) -> bool:
@@ -268,19 +342,7 @@ def kernel_timer_active() -> bool:
     return _timer is not None
 
 
-_gemm_raw = gemm
 _attn_fwd_raw, _attn_bwd_raw = attn_fwd, attn_bwd
-
-
-def gemm(layout, M, N, K, *a, **k):  # noqa: F811
-    if _timer is None:
-        return _gemm_raw(layout, M, N, K, *a, **k)
-    flags = a[6] if len(a) > 6 else k.get("flags", 0)
-    kind = "gemm_dma_kernel<NT>" if _uses_dma(layout, M, N, K, flags) else _GEMM_KERNEL[layout]
-    e0, e1 = _timer.record(kind, 2.0 * M * N * K, (M, N, K))
-    e0.record()
-    _gemm_raw(layout, M, N, K, *a, **k)
-    e1.record()
 
 
 def attn_fwd(qkv, out, lse, B, N, H, D, scale):  # noqa: F811
