@@ -41,9 +41,11 @@ int mh_version(void);
 #define MH_GEMM_RESIDUAL 8
 #define MH_GEMM_DGELU 16
 #define MH_GEMM_ATOMIC 32
+#define MH_GEMM_COLSUM 64   /* bf16 output only: colsum[(m / 64), n] = sum over the 64-row block of C[m, n] (f32 values before
+                             * rounding); colsum is a [ceil(M / 64), N] workspace, plain stores; reduce it with mh_colsum */
 int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                  int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
-                 int ldaux, void* stream);
+                 int ldaux, float* colsum, void* stream);
 
 /* Same contract with an explicit kernel / tile choice (what mh_gemm_bf16 picks by itself with MH_TILE_AUTO):
  *   MH_TILE_REG_128      128x128x64 tile, register-staged double-buffered LDS (gemm.hip): every shape / tail
@@ -56,7 +58,7 @@ enum { MH_TILE_AUTO = -1, MH_TILE_REG_128 = 0, MH_TILE_DMA_256 = 1, MH_TILE_DMA_
        MH_TILE_DMA_128 = 4 };
 int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
-                      int ldaux, void* stream);
+                      int ldaux, float* colsum, void* stream);
 
 /* Grouped weight-gradient GEMM: ONE launch over the 256x256 tiles of many independent "TN" problems
  * dW_i[M_i, N_i] (f32) = A_i^T B_i with A_i [K_i, M_i] bf16 (= dY_i), B_i [K_i, N_i] bf16 (= X_i), K_i = tokens.

@@ -262,7 +262,7 @@ static bool prefer_dma(int layout, int M, int N, int K, int flags) {
 
 extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                                  void* C, int ldc, int flags, const float* bias, const float* res, int ldr,
-                                 const void* aux_in, void* aux_out, int ldaux, void* stream) {
+                                 const void* aux_in, void* aux_out, int ldaux, float* colsum, void* stream) {
     MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_DMA_128, "mh_gemm_bf16: tile %d", tile);
     MH_CHECK_ARG(layout >= 0 && layout <= 2, "mh_gemm_bf16: layout %d", layout);
     MH_CHECK_ARG(M > 0 && N > 0 && K > 0, "mh_gemm_bf16: empty problem %d %d %d", M, N, K);
@@ -284,19 +284,20 @@ extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, cons
     MH_CHECK_ARG(!(flags & MH_GEMM_DGELU) || (aux_in && ldaux % 8 == 0), "mh_gemm_bf16: dgelu needs aux_in, ldaux %% 8 == 0");
     MH_CHECK_ARG(!(flags & MH_GEMM_GELU) || !aux_out || ldaux % 8 == 0, "mh_gemm_bf16: ldaux %% 8");
     MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || (flags & MH_GEMM_OUT_F32), "mh_gemm_bf16: atomic needs f32 output");
+    MH_CHECK_ARG(!(flags & MH_GEMM_COLSUM) || (colsum && !(flags & MH_GEMM_OUT_F32)), "mh_gemm_bf16: colsum needs a pointer and bf16 output");
     MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || !(flags & ~(MH_GEMM_ATOMIC | MH_GEMM_OUT_F32)),
                  "mh_gemm_bf16: atomic accumulate excludes other epilogues");
 
     if (tile > MH_TILE_REG_128)   // explicit DMA tile: -2 when not eligible (the caller picks another tile)
-        return gemm_dma_dispatch(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, stream);
+        return gemm_dma_dispatch(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, stream);
     if (tile == MH_TILE_AUTO && prefer_dma(layout, M, N, K, flags)) {
         const int rc = gemm_dma_dispatch(MH_TILE_DMA_256, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in,
-                                         aux_out, ldaux, stream);
+                                         aux_out, ldaux, colsum, stream);
         if (rc != -2) return rc;   // -2: not eligible -> general kernel below
     }
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
-    p.bias = bias; p.res = res; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out;
+    p.bias = bias; p.res = res; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.colsum = colsum;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.flags = flags;
     p.tiles_m = ceil_div(M, BM); p.tiles_n = ceil_div(N, BN);
     int splits = 1;
@@ -332,7 +333,7 @@ extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, cons
 
 extern "C" int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                             int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in,
-                            void* aux_out, int ldaux, void* stream) {
+                            void* aux_out, int ldaux, float* colsum, void* stream) {
     return mh_gemm_bf16_tile(MH_TILE_AUTO, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out,
-                             ldaux, stream);
+                             ldaux, colsum, stream);
 }

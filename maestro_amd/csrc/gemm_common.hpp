@@ -7,7 +7,7 @@
 
 struct GemmParams {
     const bf16_t* A; const bf16_t* B; void* C;
-    const float* bias; const float* res; const bf16_t* aux_in; bf16_t* aux_out;
+    const float* bias; const float* res; const bf16_t* aux_in; bf16_t* aux_out; float* colsum;
     int M, N, K, lda, ldb, ldc, ldr, ldaux, flags;
     int tiles_m, tiles_n, k_per_split;
     int fast;               // 1: buffer-load path (no K tail inside a K-minor operand, extents < 2 GiB)
@@ -17,7 +17,7 @@ struct GemmParams {
 // gemm_dma.hip: the LDS-DMA tile family (tile = MH_TILE_DMA_*); -2 = not eligible, nothing launched
 int gemm_dma_dispatch(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
-                      int ldaux, void* stream);
+                      int ldaux, float* colsum, void* stream);
 
 // Row-major epilogue: each wave transposes its tile through a private LDS region (passes of 32 rows, 68-float row pitch:
 // conflict-free ds_write_b128 / ds_read_b128) so that the bias / residual / aux reads and the C / aux writes are done in
@@ -27,6 +27,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                                                     int n_base) {
     const int l = threadIdx.x & 63, g = l >> 4, lm = l & 15;
     const bool out_f32 = p.flags & MH_GEMM_OUT_F32;
+    f32x4 cs_lo = {0, 0, 0, 0}, cs_hi = {0, 0, 0, 0};   // MH_GEMM_COLSUM: this lane's 8 columns summed over its rows
 #pragma unroll
     for (int pass_m = 0; pass_m < MT / 2; ++pass_m) {
 #pragma unroll
@@ -79,9 +80,29 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                         hi[2] *= gelu_erf_grad(__uint_as_float(pk[3] << 16));
                         hi[3] *= gelu_erf_grad(__uint_as_float(pk[3] & 0xffff0000u));
                     }
+                    cs_lo += lo; cs_hi += hi;
                     u32x4 pk = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
                     *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
                 }
+            }
+            if ((p.flags & MH_GEMM_COLSUM) && (pass_m & 1)) {
+                // one 64-row block done: lanes with equal (l & 7) hold the same 8 columns -> fold the 8 row groups and
+                // store the block's partial column sums as row (m / 64) of the [ceil(M / 64), N] workspace (no atomics)
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        cs_lo[e] += __shfl_xor(cs_lo[e], o, 64);
+                        cs_hi[e] += __shfl_xor(cs_hi[e], o, 64);
+                    }
+                }
+                const int m_blk = m_base + 32 * (pass_m - 1);
+                if (l < 8 && n < p.N && m_blk < p.M) {
+                    float* dst = p.colsum + (size_t)(m_blk >> 6) * p.N + n;
+                    *reinterpret_cast<f32x4*>(dst) = cs_lo;
+                    *reinterpret_cast<f32x4*>(dst + 4) = cs_hi;
+                }
+                cs_lo = (f32x4){0, 0, 0, 0}; cs_hi = (f32x4){0, 0, 0, 0};
             }
         }
     }

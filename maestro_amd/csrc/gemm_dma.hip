@@ -186,7 +186,7 @@ __global__ __launch_bounds__(T::NT) void gemm_dma_grouped_tn_kernel(const MhGrou
     const MhGroupedGemm g = table[i];
     GemmParams p;
     p.A = (const bf16_t*)g.A; p.B = (const bf16_t*)g.B; p.C = g.C;
-    p.bias = nullptr; p.res = nullptr; p.aux_in = nullptr; p.aux_out = nullptr;
+    p.bias = nullptr; p.res = nullptr; p.aux_in = nullptr; p.aux_out = nullptr; p.colsum = nullptr;
     p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.ldr = 0; p.ldaux = 0;
     p.flags = MH_GEMM_OUT_F32 | (g.accumulate ? MH_GEMM_ATOMIC : 0);
     p.tiles_m = (g.M + T::BM - 1) / T::BM; p.tiles_n = (g.N + T::BN - 1) / T::BN; p.k_per_split = g.K; p.fast = 1;
@@ -235,13 +235,13 @@ extern "C" int mh_gemm_grouped_tn(const MhGroupedGemm* table_device, int n_probl
 // error string) when the problem does not qualify for the DMA path, so that the caller can use the general kernel.
 int gemm_dma_dispatch(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
-                      int ldaux, void* stream) {
+                      int ldaux, float* colsum, void* stream) {
     const bool a_kmajor = layout == 2, b_kmajor = layout != 0;
     if ((!a_kmajor || !b_kmajor) && K % BK != 0) return -2;   // a K tail inside a K-minor row would wrap, not read zero
     if (lda % 8 || ldb % 8) return -2;
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
-    p.bias = bias; p.res = res; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out;
+    p.bias = bias; p.res = res; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.colsum = colsum;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.flags = flags;
     const long a_ext = a_kmajor ? ((long)(K - 1) * lda + M) * 2 : ((long)(M - 1) * lda + K) * 2;
     const long b_ext = b_kmajor ? ((long)(K - 1) * ldb + N) * 2 : ((long)(N - 1) * ldb + K) * 2;

@@ -86,27 +86,57 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         gm[i] = c < nv ? *reinterpret_cast<const f32x4*>(gamma + 4 * c) : (f32x4){0, 0, 0, 0};
     }
     const int row0 = (blockIdx.x * 4 + w) * ROWS_PER_WAVE;
+    const int rows = B * n;
+    // Software pipeline over the wave's rows: every operand of row r+1 (x, dy and the residual gradient) is requested
+    // before row r is reduced, so a wave keeps two rows of loads in flight instead of two dependent round trips per row.
+    f32x4 xv_n[NV], rs_n[NV];
+    u32x4 dy_n[NV];      // bf16: .xy hold 4 values; f32: all four lanes
+    float mu_n = 0.f, rstd_n = 0.f;
+    size_t xrow_n = 0;
+    auto fetch = [&](int row) {
+        const int b = row / n, j = row - b * n;
+        xrow_n = map_row(xm, b, j) * dim;
+        const size_t dyrow = map_row(dym, b, j) * dim;
+        mu_n = mean[row]; rstd_n = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                xv_n[i] = *reinterpret_cast<const f32x4*>(x + xrow_n + 4 * c);
+                if (dy_is_f32) {
+                    dy_n[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(dy) + dyrow + 4 * c);
+                } else {
+                    const u32x2 pk = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(dy) + dyrow + 4 * c);
+                    dy_n[i] = (u32x4){pk[0], pk[1], 0u, 0u};
+                }
+                rs_n[i] = dres ? *reinterpret_cast<const f32x4*>(dres + xrow_n + 4 * c) : (f32x4){0, 0, 0, 0};
+            }
+        }
+    };
+    if (row0 < rows) fetch(row0);
     for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
         const int row = row0 + rr;
-        if (row >= B * n) break;
-        const int b = row / n, j = row - b * n;
-        const size_t xrow = map_row(xm, b, j) * dim, dyrow = map_row(dym, b, j) * dim;
-        const float mu = mean[row], rs = rstd[row];
-        f32x4 xh[NV], dz[NV];
+        if (row >= rows) break;
+        const size_t xrow = xrow_n;
+        const float mu = mu_n, rs = rstd_n;
+        f32x4 xh[NV], dz[NV], rsd[NV];
+        u32x4 dyv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { xh[i] = xv_n[i]; dyv[i] = dy_n[i]; rsd[i] = rs_n[i]; }
+        if (rr + 1 < ROWS_PER_WAVE && row + 1 < rows) fetch(row + 1);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
+            const f32x4 xv = xh[i];
             xh[i] = (f32x4){0, 0, 0, 0}; dz[i] = (f32x4){0, 0, 0, 0};
             if (c < nv) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + xrow + 4 * c);
                 f32x4 d;
                 if (dy_is_f32) {
-                    d = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dy) + dyrow + 4 * c);
+                    d = __builtin_bit_cast(f32x4, dyv[i]);
                 } else {
-                    const u32x2 pk = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(dy) + dyrow + 4 * c);
-                    d = (f32x4){__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
-                                __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+                    d = (f32x4){__uint_as_float(dyv[i][0] << 16), __uint_as_float(dyv[i][0] & 0xffff0000u),
+                                __uint_as_float(dyv[i][1] << 16), __uint_as_float(dyv[i][1] & 0xffff0000u)};
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -127,7 +157,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (dz[i][e] - c1 - xh[i][e] * c2);
-                if (dres) o += *reinterpret_cast<const f32x4*>(dres + xrow + 4 * c);
+                o += rsd[i];
                 csum[i] += o;
                 *reinterpret_cast<f32x4*>(dx + xrow + 4 * c) = o;
                 if (dx_bf16) {

@@ -17,6 +17,7 @@ Pipeline (reference ``maestro/ssl/mim.py:473-505`` + ``maestro/train/model.py:19
 
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -113,6 +114,8 @@ class Stack:
         self.dx0_16 = e(M, dim, dt=BF16)                                  # bf16 gradient w.r.t. x0
         self.dh2, self.do, self.delta = e(M, dim, dt=BF16), e(M, self.inner, dt=BF16), e(Bn * self.H * N)
         self.ln_ws = e(max(1, hip.layernorm_bwd_workspace(M, dim)))  # private: stacks of different groups run concurrently
+        self.cs_rows = (M + 63) // 64
+        self.cs_ws = e(self.cs_rows, mlp)     # per-64-row-block column sums of d fc1-out (GEMM epilogue side output)
 
     @property
     def x0(self):
@@ -190,12 +193,12 @@ class Stack:
             nxt = self.dxa if mid is not self.dxa else self.dxb
             nxt16 = self.saved[l - 1]["gy16"] if l > 0 else self.dx0_16
             # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-            hip.gemm(hip.GEMM_NN, M, mlp, dim, cur16, dim, ps.h(fc2.weight), mlp, dh, mlp, hip.DGELU, aux_in=s["hpre"],
-                     ldaux=mlp)
+            hip.gemm(hip.GEMM_NN, M, mlp, dim, cur16, dim, ps.h(fc2.weight), mlp, dh, mlp, hip.DGELU | hip.COLSUM,
+                     aux_in=s["hpre"], ldaux=mlp, colsum=self.cs_ws)
+            hip.colsum(self.cs_ws, ps.g(fc1.bias), self.cs_rows, mlp, mlp)   # fc1 bias gradient from the block partials
             if not defer:
                 hip.gemm(hip.GEMM_TN, dim, mlp, M, cur16, dim, s["act"], mlp, ps.g(fc2.weight), mlp, AT)
                 hip.gemm(hip.GEMM_TN, mlp, dim, M, dh, mlp, s["h2"], dim, ps.g(fc1.weight), dim, AT)
-            hip.colsum(dh, ps.g(fc1.bias), M, mlp, mlp)
             hip.gemm(hip.GEMM_NN, M, dim, mlp, dh, mlp, ps.h(fc1.weight), dim, self.dh2, dim)
             hip.layernorm_bwd(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16,
                               ps.g(ln2.weight), ps.g(ln2.bias), ps.g(proj.bias), self.ln_ws, 1, M, dim)
@@ -242,6 +245,12 @@ class MAEEngine:
         if self.wgrad_mode not in ("auto", "fused", "deferred"):
             raise ValueError(f"MAESTRO_WGRAD={self.wgrad_mode!r}: expected auto, fused or deferred")
         self._wgrad_tables, self._wgrad_plans = {}, {}
+        # MAESTRO_TUNE=1: the first forward / backward run eagerly on one stream with GEMM tile tuning on: every distinct GEMM
+        # signature of the step times the kernel tiles on its own operands once and keeps the fastest (hip.set_gemm_tuning).
+        # Off by default: on C3 the isolated timings pick tiles that are 1 % slower inside the two-stream step than the
+        # library's own rule (1291 vs 1303 tiles/s, same box).
+        self.tune_gemm = os.environ.get("MAESTRO_TUNE", "0") == "1"
+        self._tuned = set()
         if os.environ.get("MAESTRO_GROUP_STREAMS") == "0":
             self.group_streams = False
         self._graphs, self._seen, self._ready_spans = {}, {}, []
@@ -362,6 +371,21 @@ class MAEEngine:
         for side in sides:
             main.wait_stream(side)
 
+    @contextlib.contextmanager
+    def _tuning_pass(self, what: str):
+        if not self.tune_gemm or what in self._tuned or hip.kernel_timer_active():
+            yield
+            return
+        saved = self.multi_stream
+        self.multi_stream = False
+        hip.set_gemm_tuning(True)
+        try:
+            yield
+        finally:
+            hip.set_gemm_tuning(False)
+            self.multi_stream = saved
+            self._tuned.add(what)
+
     def _segment(self, name: str, key, fn) -> None:
         """Run one launch segment: eagerly, or as a captured hipGraph replay when the input addresses are unchanged."""
         if not self.use_graphs or hip.kernel_timer_active():
@@ -449,7 +473,8 @@ class MAEEngine:
                 raise ValueError(f"batch['{s.name}_dates'] must be a contiguous int16 tensor [B, D, 3]")
         self._staged = batch
         key = self._cur_key = tuple(batch[k].data_ptr() for k in sorted(batch) if isinstance(batch[k], torch.Tensor))
-        self._segment("forward", key, lambda: self._forward_launches(batch))
+        with self._tuning_pass("forward"):
+            self._segment("forward", key, lambda: self._forward_launches(batch))
         return self.loss_acc
 
     def _forward_launches(self, batch: dict) -> None:
@@ -600,13 +625,14 @@ class MAEEngine:
         key = getattr(self, "_cur_key", None)
         plan = self._plan = self._wgrad_plan()
         sfx = f":{plan}:{'h' if self.grad_hook is not None else 'n'}"   # graphs are specific to the launch plan
-        self._segment("bwd_dec" + sfx, key, self._bwd_decoder_side)
-        if self.joint is not None:
-            self._segment("bwd_joint" + sfx, key, self._bwd_joint)
-        cuts = self._enc_cuts()
-        for i in range(len(cuts) - 1):
-            self._segment(f"bwd_enc{i}" + sfx, key, lambda hi=cuts[i], lo=cuts[i + 1], first=(i == 0), last=(i == len(cuts) - 2):
-                          self._bwd_encoder_side(hi, lo, first, last))
+        with self._tuning_pass("backward"):
+            self._segment("bwd_dec" + sfx, key, self._bwd_decoder_side)
+            if self.joint is not None:
+                self._segment("bwd_joint" + sfx, key, self._bwd_joint)
+            cuts = self._enc_cuts()
+            for i in range(len(cuts) - 1):
+                self._segment(f"bwd_enc{i}" + sfx, key, lambda hi=cuts[i], lo=cuts[i + 1], first=(i == 0), last=(i == len(cuts) - 2):
+                              self._bwd_encoder_side(hi, lo, first, last))
 
     def _bwd_decoder_side(self) -> None:
         m, E, Dd, ps = self.model, self.E, self.Dd, self.store  # noqa: N806

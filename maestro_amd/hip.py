@@ -17,7 +17,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libmaestro_hip.so"
 _lib = None
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-OUT_F32, BIAS, GELU, RESIDUAL, DGELU, ATOMIC = 1, 2, 4, 8, 16, 32
+OUT_F32, BIAS, GELU, RESIDUAL, DGELU, ATOMIC, COLSUM = 1, 2, 4, 8, 16, 32, 64
 
 
 class HipExtensionError(RuntimeError):
@@ -80,10 +80,10 @@ def gemm_tile_choices() -> dict:
     return dict(_tile_choice)
 
 
-def _gemm_tile(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux) -> int:  # noqa: N803
+def _gemm_tile(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum) -> int:  # noqa: N803
     return lib().mh_gemm_bf16_tile(_I(tile), _I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C),
                                    _I(ldc), _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux),
-                                   stream())
+                                   ptr(colsum), stream())
 
 
 def _tune_gemm(key, args) -> int:
@@ -108,14 +108,19 @@ def _tune_gemm(key, args) -> int:
 
 
 def _pick_tile(layout, M, N, K, flags, args) -> int:  # noqa: N803
-    key = (layout, M, N, K, flags)
+    tflags = flags & ~COLSUM                 # the column-sum side output does not change the kernel's cost profile
+    key = (layout, M, N, K, tflags)
     tile = _tile_choice.get(key)
     if tile is None:
         forced = os.environ.get("MH_GEMM_TILE")
         if forced is not None:
             return int(forced)
-        # atomically accumulated outputs cannot be re-run for timing: the library's own rule decides
-        tile = _tune_gemm(key, args) if _tuning and not (flags & ATOMIC) else TILE_AUTO
+        if _tuning and not (flags & ATOMIC):   # accumulating outputs cannot be re-run for timing: the library's rule decides
+            targs = list(args)
+            targs[10], targs[17] = tflags, None
+            tile = _tune_gemm(key, tuple(targs))
+        else:
+            tile = TILE_AUTO
     return tile
 
 
@@ -124,10 +129,10 @@ def _auto_tile_name(layout, M, N, K, flags) -> int:  # noqa: N803
 
 
 def gemm(layout: int, M: int, N: int, K: int, A, lda: int, B, ldb: int, C, ldc: int, flags: int = 0, bias=None,  # noqa: N803
-         res=None, ldr: int = 0, aux_in=None, aux_out=None, ldaux: int = 0, tile: int | None = None) -> None:
+         res=None, ldr: int = 0, aux_in=None, aux_out=None, ldaux: int = 0, colsum=None, tile: int | None = None) -> None:
     """``tile``: one of TILE_* to force a kernel (tests / micro-benchmarks); default = the tuned choice for this problem
     signature if there is one, else the library's own rule (MH_TILE_AUTO)."""
-    args = (layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux)
+    args = (layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum)
     explicit = tile is not None
     if not explicit:
         tile = _pick_tile(layout, M, N, K, flags, args)

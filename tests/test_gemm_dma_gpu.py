@@ -130,3 +130,24 @@ def test_tuned_tile_choice_is_recorded_and_exact():
     hip.gemm(0, M, N, K, A, K, B, K, C, N, hip.OUT_F32)
     torch.cuda.synchronize()
     assert torch.equal(C, want)
+
+
+@pytest.mark.parametrize("tile", [0] + DMA_TILES)
+def test_gemm_colsum_side_output(tile):
+    """MH_GEMM_COLSUM: the epilogue stores per-64-row-block column sums of the (pre-rounding) bf16 output."""
+    from maestro_amd import hip
+    dev = _dev()
+    M, N, K = 1000, 520, 256          # ragged in both tile dimensions
+    A, B, want = _operands(1, M, N, K, dev, integer=True)
+    aux = (torch.randn(M, N, device=dev) * 0.5).bfloat16()
+    C = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    acc = torch.full(((M + 63) // 64, N), float("nan"), device=dev)
+    hip.gemm(1, M, N, K, A, K, B, N, C, N, hip.DGELU | hip.COLSUM, aux_in=aux, ldaux=N, colsum=acc, tile=tile)
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    ref = want * x.grad
+    assert (C.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    pad = torch.zeros(acc.shape[0] * 64, N, device=dev)
+    pad[:M] = ref
+    exp = pad.view(-1, 64, N).sum(1)
+    assert (acc - exp).abs().max() <= 1e-3 * ref.abs().sum(0).max(), (acc - exp).abs().max().item()
