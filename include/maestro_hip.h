@@ -63,14 +63,18 @@ int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, 
 /* Grouped weight-gradient GEMM: ONE launch over the 256x256 tiles of many independent "TN" problems
  * dW_i[M_i, N_i] (f32) = A_i^T B_i with A_i [K_i, M_i] bf16 (= dY_i), B_i [K_i, N_i] bf16 (= X_i), K_i = tokens.
  * Used to issue all wgrads of a backward segment at once (no split-K, whole-chip tile occupancy).  `table` is a DEVICE
- * array; tile_begin is the exclusive prefix sum of ceil(M/256)*ceil(N/256); M, N, lda, ldb %% 8 == 0.  accumulate = 0:
- * plain stores (the entry is the only writer of C); 1: fp32 atomic adds into a zeroed C (several entries share one C,
- * e.g. one encoder applied to several groups). */
+ * array of problems; M, N, lda, ldb %% 8 == 0.  accumulate = 0: plain stores (the entry is the only writer of C); 1: fp32
+ * atomic adds into a zeroed C (several entries share one C, e.g. one encoder applied to several groups).
+ * `tile_queues` is a DEVICE array [8][queue_len] of tile ids (problem << 16 | tile_m << 8 | tile_n, 0xFFFFFFFF = empty
+ * slot), one queue per XCD: workgroup b runs entry [b %% 8][b / 8] (the hardware places workgroup b on XCD b %% 8), so the
+ * host decides which tiles share an L2: keep the tiles of one problem in one queue (its dY / X panels are then fetched
+ * once per XCD instead of once per tile) and balance sum(K) over the queues. */
 typedef struct MhGroupedGemm {
     const void* A; const void* B; void* C;
-    int M, N, K, lda, ldb, ldc, tile_begin, accumulate;
+    int M, N, K, lda, ldb, ldc, reserved, accumulate;
 } MhGroupedGemm;
-int mh_gemm_grouped_tn(const MhGroupedGemm* table_device, int n_problems, int total_tiles, void* stream);
+int mh_gemm_grouped_tn(const MhGroupedGemm* table_device, int n_problems, const uint32_t* tile_queues, int queue_len,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------- LayerNorm
  * y = (x - mean) * rstd * gamma + beta over the last dim; x f32 (residual stream), y bf16 (GEMM operand) or f32.

@@ -175,15 +175,16 @@ typedef Tile<1, 4, 3> T128x256;  // 128 x 256
 typedef Tile<1, 2, 4> T128;      // 128 x 128
 
 // Grouped weight-gradient launch: ONE grid over the 256x256 tiles of many independent TN problems
-// (dW_i[M_i, N_i] = dY_i^T X_i, K_i = tokens), no split-K.  Workgroup b finds its problem by a scalar scan of the tile
-// prefix (a few dozen entries) and runs the same tile routine.
+// (dW_i[M_i, N_i] = dY_i^T X_i, K_i = tokens), no split-K.  Workgroup b (placed on XCD b % 8 by the hardware) runs entry
+// b / 8 of that XCD's host-built tile queue, so that the tiles of one problem run side by side under one L2 and sweep
+// K together: a dY / X panel is then fetched from HBM once per problem instead of once per tile.
 template <class T>
-__global__ __launch_bounds__(T::NT) void gemm_dma_grouped_tn_kernel(const MhGroupedGemm* __restrict__ table, int n_problems) {
+__global__ __launch_bounds__(T::NT) void gemm_dma_grouped_tn_kernel(const MhGroupedGemm* __restrict__ table, int n_problems,
+                                                                    const uint32_t* __restrict__ queues, int queue_len) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[T::LDS_BYTES];
-    const int b = blockIdx.x;
-    int i = 0;
-    while (i + 1 < n_problems && table[i + 1].tile_begin <= b) ++i;   // uniform: scalar loads
-    const MhGroupedGemm g = table[i];
+    const uint32_t e = queues[(size_t)(blockIdx.x & 7) * queue_len + (blockIdx.x >> 3)];   // uniform: scalar load
+    if (e == 0xFFFFFFFFu || (int)(e >> 16) >= n_problems) return;
+    const MhGroupedGemm g = table[e >> 16];
     GemmParams p;
     p.A = (const bf16_t*)g.A; p.B = (const bf16_t*)g.B; p.C = g.C;
     p.bias = nullptr; p.res = nullptr; p.aux_in = nullptr; p.aux_out = nullptr; p.colsum = nullptr;
@@ -192,8 +193,9 @@ __global__ __launch_bounds__(T::NT) void gemm_dma_grouped_tn_kernel(const MhGrou
     p.tiles_m = (g.M + T::BM - 1) / T::BM; p.tiles_n = (g.N + T::BN - 1) / T::BN; p.k_per_split = g.K; p.fast = 1;
     p.a_bytes = (unsigned)(((long)(g.K - 1) * g.lda + g.M) * 2);
     p.b_bytes = (unsigned)(((long)(g.K - 1) * g.ldb + g.N) * 2);
-    const int t = b - g.tile_begin;                     // consecutive workgroups share the A panel (same tile_m)
-    gemm_dma_tile<T, true, true, 1>(p, t / p.tiles_n, t % p.tiles_n, 0, g.K, smem);
+    const int tile_m = (e >> 8) & 0xff, tile_n = e & 0xff;
+    if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
+    gemm_dma_tile<T, true, true, 1>(p, tile_m, tile_n, 0, g.K, smem);
 }
 
 template <class T>
@@ -224,9 +226,12 @@ int launch_dma(int layout, GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int mh_gemm_grouped_tn(const MhGroupedGemm* table_device, int n_problems, int total_tiles, void* stream) {
-    MH_CHECK_ARG(table_device && n_problems > 0 && total_tiles > 0, "mh_gemm_grouped_tn: bad arguments");
-    hipLaunchKernelGGL(gemm_dma_grouped_tn_kernel<T256>, dim3(total_tiles), dim3(T256::NT), 0, (hipStream_t)stream, table_device, n_problems);
+extern "C" int mh_gemm_grouped_tn(const MhGroupedGemm* table_device, int n_problems, const uint32_t* tile_queues,
+                                  int queue_len, void* stream) {
+    MH_CHECK_ARG(table_device && tile_queues && n_problems > 0 && n_problems < 65536 && queue_len > 0,
+                 "mh_gemm_grouped_tn: bad arguments");
+    hipLaunchKernelGGL(gemm_dma_grouped_tn_kernel<T256>, dim3(8 * queue_len), dim3(T256::NT), 0, (hipStream_t)stream,
+                       table_device, n_problems, tile_queues, queue_len);
     MH_LAUNCH_CHECK();
     return 0;
 }

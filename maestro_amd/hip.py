@@ -372,7 +372,7 @@ def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):  # noqa: F811
 class _MhGroupedGemm(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("M", ctypes.c_int),
                 ("N", ctypes.c_int), ("K", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int),
-                ("tile_begin", ctypes.c_int), ("accumulate", ctypes.c_int)]
+                ("reserved", ctypes.c_int), ("accumulate", ctypes.c_int)]
 
 
 class GroupedTN:
@@ -396,32 +396,58 @@ class GroupedTN:
     def count_tiles(problems) -> int:
         return sum(GroupedTN.check(i, p) for i, p in enumerate(problems))
 
+    N_XCD = 8
+
     def __init__(self, problems, device) -> None:
-        # longest-first: workgroups are dispatched in tile order and a tile's duration is proportional to its K
-        problems = sorted(problems, key=lambda p: -p[5])
         arr = (_MhGroupedGemm * len(problems))()
-        tiles = 0
         self.keep = []
         writers = {}
         for prob in problems:
             writers[prob[2].data_ptr()] = writers.get(prob[2].data_ptr(), 0) + 1
+        units = []   # (work, problem index, tiles_m, tiles_n)
         for i, prob in enumerate(problems):
             A, B, C, M, N, K, lda, ldb, ldc = prob  # noqa: N806
             n = self.check(i, prob)
             shared = int(writers[C.data_ptr()] > 1)   # several problems add into one (zeroed) dW: atomic epilogue
-            arr[i] = _MhGroupedGemm(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, lda, ldb, ldc, tiles, shared)
-            tiles += n
+            arr[i] = _MhGroupedGemm(A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, lda, ldb, ldc, 0, shared)
+            units.append((n * K, i, -(-M // 256), -(-N // 256)))
             self.keep += [A, B, C]
+        # One tile queue per XCD.  Whole problems go to the least-loaded queue, largest first (work = tiles x K), so that a
+        # problem's tiles run under one L2 at the same time and share their dY / X panels; a problem bigger than half a
+        # queue's fair share is dealt out by rows of tiles (one dY panel each) instead.
+        fair = sum(u[0] for u in units) / self.N_XCD
+        pieces = []  # (work, K, [tile ids])
+        for work, i, tm, tn in units:
+            K = problems[i][5]  # noqa: N806
+            rows = [[(i << 16) | (r << 8) | c for c in range(tn)] for r in range(tm)]
+            if work > 0.5 * fair and tm > 1:
+                pieces += [(tn * K, K, row) for row in rows]
+            else:
+                pieces.append((work, K, [t for row in rows for t in row]))
+        load = [0.0] * self.N_XCD
+        queues = [[] for _ in range(self.N_XCD)]
+        for work, K, ids in sorted(pieces, key=lambda p: -p[0]):  # noqa: N806
+            x = min(range(self.N_XCD), key=load.__getitem__)
+            load[x] += work
+            queues[x].append((K, ids))
+        qlen = max(sum(len(ids) for _, ids in q) for q in queues)
+        flat = torch.full((self.N_XCD, qlen), 0xFFFFFFFF, dtype=torch.int64)
+        for x, q in enumerate(queues):
+            ids = [t for _, tiles in sorted(q, key=lambda e: -e[0]) for t in tiles]   # longest tiles first
+            flat[x, : len(ids)] = torch.tensor(ids, dtype=torch.int64)
+        self.queues = flat.to(torch.uint32).to(device)
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.table = raw.to(device)
-        self.n, self.tiles = len(problems), tiles
+        self.n, self.queue_len = len(problems), qlen
+        self.tiles = sum(u[2] * u[3] for u in units)
+        self.balance = max(load) / max(fair, 1e-9)       # 1.0 = perfectly even queues
         self.flops = sum(2.0 * M * N * K for (_, _, _, M, N, K, _, _, _) in problems)
 
     def launch(self) -> None:
         if _timer is None:
-            call("mh_gemm_grouped_tn", self.table, _I(self.n), _I(self.tiles))
+            call("mh_gemm_grouped_tn", self.table, _I(self.n), self.queues, _I(self.queue_len))
             return
         e0, e1 = _timer.record("gemm_dma_grouped_tn_kernel", self.flops, ("grouped", self.n, self.tiles))
         e0.record()
-        call("mh_gemm_grouped_tn", self.table, _I(self.n), _I(self.tiles))
+        call("mh_gemm_grouped_tn", self.table, _I(self.n), self.queues, _I(self.queue_len))
         e1.record()

@@ -15,11 +15,24 @@ src, dst = root / "gpurun_out" / "prof", root / "profiles"
 dst.mkdir(exist_ok=True)
 shutil.copy(src / f"{tag}_kernel_stats.csv", dst / f"{tag}_kernel_stats.csv")
 
+_LAYOUT = {("false", "false"): "NT", ("false", "true"): "NN", ("true", "true"): "TN"}
+_TILE = {"2, 4, 4": "256x256", "2, 2, 3": "256x128", "1, 4, 3": "128x256", "1, 2, 4": "128x128"}
+
+
 def short(name):
+    """rocprof kernel name -> the label maestro_amd.hip.KernelTimer / bench.py use for the same kernel."""
+    import re
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    name = name.replace("gemm_kernel<false, false>", "gemm_kernel<NT>").replace("gemm_kernel<false, true>", "gemm_kernel<NN>")
-    name = name.replace("gemm_kernel<true, true>", "gemm_kernel<TN>")
+    m = re.match(r"gemm_kernel<(\w+), (\w+)>", name)
+    if m:
+        return f"gemm_kernel<{_LAYOUT[m.groups()]}>"
+    m = re.match(r"gemm_dma_kernel<Tile<([\d, ]+)>, (\w+), (\w+)>", name)
+    if m:
+        return f"gemm_dma_kernel<{_TILE[m.group(1)]},{_LAYOUT[(m.group(2), m.group(3))]}>"
+    if name.startswith("gemm_dma_grouped_tn_kernel"):
+        return "gemm_dma_grouped_tn_kernel"
     return name.split("(")[0]
+
 
 agg = collections.defaultdict(lambda: {"launches": 0, "FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0})
 for kind, col in (("fetch", "FETCH_SIZE_KB"), ("write", "WRITE_SIZE_KB")):
