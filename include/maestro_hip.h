@@ -138,6 +138,11 @@ int mh_date_features(const int16_t* dates, const int16_t* ref_date, float* out, 
 /* Input staging: resize rasters to image_size (maestro/ssl/mim.py:427-432, F.interpolate with align_corners=False).
  * in f32 [planes, Hin, Win] -> out f32 [planes, Hout, Wout]; mode 0 nearest, 1 bilinear (PyTorch index maps). */
 int mh_resize(const float* in, float* out, long planes, int Hin, int Win, int Hout, int Wout, int mode, void* stream);
+/* Input staging: per-sample flips / transpose of square rasters (maestro/dataset/dataset.py:224-257: np.flip axis 2, np.flip
+ * axis 3, np.swapaxes(2, 3) of the per-sample [D, C, H, W] array, applied in that order).  in/out [B, planes, S, S] of
+ * elem_bytes-wide elements (1, 2, 4, 8), out of place; flags[b] bit0 = flip rows, bit1 = flip columns, bit2 = transpose.
+ * Pure data movement: bit-exact. */
+int mh_dihedral(const void* in, void* out, const uint8_t* flags, int B, long planes, int S, int elem_bytes, void* stream);
 /* Elevation rescale copy (maestro/ssl/mim.py:433-436): out[:, c>=1] = 30 * (img[:, 0] - img[:, c]); out != img. */
 int mh_rescale_elev(const float* img, float* out, int BD, int C, int S, void* stream);
 /* Patch layout [BD*g*g, P*P*C] -> image [BD, C, S, S] ('(p1 p2 c) h w -> c (h p1) (w p2)', embed.py:153-160). */

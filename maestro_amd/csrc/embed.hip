@@ -268,6 +268,37 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
              ly * (hx * src[(long)y1 * Win + x0] + lx * src[(long)y1 * Win + x1]);
 }
 
+// ---- per-sample dihedral augmentation of square rasters (maestro/dataset/dataset.py:224-257: flip axis 2, flip axis 3,
+// swap axes 2 and 3 of the per-sample [D, C, H, W] array, in that order).  flags[b]: bit0 = flip rows, bit1 = flip columns,
+// bit2 = transpose.  out[y, x] = in[yy, xx] with (yy, xx) = transpose ? (x, y) : (y, x), then xx -> S-1-xx if bit1,
+// yy -> S-1-yy if bit0.  32x32 tiles through LDS so that the transposed case still reads and writes whole row segments.
+template <typename T>
+__global__ __launch_bounds__(256) void dihedral_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                       const uint8_t* __restrict__ flags, int S, long planes) {
+    __shared__ T tile[32][33];
+    const int b = blockIdx.z, f = flags[b], tiles = (S + 31) / 32;
+    const bool fh = f & 1, fw = f & 2, tr = f & 4;
+    const int ty = blockIdx.x / tiles, tx = blockIdx.x % tiles;
+    const size_t base = ((size_t)b * planes + blockIdx.y) * S * S;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    if (!tr) {
+        for (int j = ly; j < 32; j += 8) {
+            const int y = ty * 32 + j, x = tx * 32 + lx;
+            if (y < S && x < S) out[base + (size_t)y * S + x] = in[base + (size_t)(fh ? S - 1 - y : y) * S + (fw ? S - 1 - x : x)];
+        }
+        return;
+    }
+    for (int j = ly; j < 32; j += 8) {
+        const int dx = tx * 32 + j, dy = ty * 32 + lx;      // destination column / row served by this source element
+        if (dx < S && dy < S) tile[j][lx] = in[base + (size_t)(fh ? S - 1 - dx : dx) * S + (fw ? S - 1 - dy : dy)];
+    }
+    __syncthreads();
+    for (int j = ly; j < 32; j += 8) {
+        const int y = ty * 32 + j, x = tx * 32 + lx;
+        if (y < S && x < S) out[base + (size_t)y * S + x] = tile[lx][j];
+    }
+}
+
 }  // namespace
 
 extern "C" int mh_resize(const float* in, float* out, long planes, int Hin, int Win, int Hout, int Wout, int mode, void* stream) {
@@ -276,6 +307,24 @@ extern "C" int mh_resize(const float* in, float* out, long planes, int Hin, int 
     const long total = planes * Hout * Wout;
     hipLaunchKernelGGL(resize_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, Hin, Win, Hout, Wout,
                        mode, total);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_dihedral(const void* in, void* out, const uint8_t* flags, int B, long planes, int S, int elem_bytes,
+                           void* stream) {
+    MH_CHECK_ARG(in && out && in != out && flags && B > 0 && B < 65536 && planes > 0 && planes < 65536 && S > 0,
+                 "mh_dihedral: bad arguments (out of place, B and planes per sample < 65536)");
+    const int tiles = ceil_div(S, 32);
+    dim3 grid(tiles * tiles, (unsigned)planes, B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (elem_bytes) {
+        case 1: hipLaunchKernelGGL(dihedral_kernel<uint8_t>, grid, block, 0, s, (const uint8_t*)in, (uint8_t*)out, flags, S, planes); break;
+        case 2: hipLaunchKernelGGL(dihedral_kernel<uint16_t>, grid, block, 0, s, (const uint16_t*)in, (uint16_t*)out, flags, S, planes); break;
+        case 4: hipLaunchKernelGGL(dihedral_kernel<uint32_t>, grid, block, 0, s, (const uint32_t*)in, (uint32_t*)out, flags, S, planes); break;
+        case 8: hipLaunchKernelGGL(dihedral_kernel<uint64_t>, grid, block, 0, s, (const uint64_t*)in, (uint64_t*)out, flags, S, planes); break;
+        default: return mh_fail(-1, "mh_dihedral: element size %d (1, 2, 4 or 8 bytes)", elem_bytes);
+    }
     MH_LAUNCH_CHECK();
     return 0;
 }

@@ -257,6 +257,15 @@ def masked_loss(rec, target, mask_group, n_masked, weight, acc, drec, B, Lm, Lgr
          _I(tok_off), _I(PPC), _I(p))
 
 
+def dihedral(x, out, flags):
+    """Per-sample flips / transpose of square rasters ``x [B, ..., S, S]`` into ``out`` (same shape); ``flags`` uint8 [B]."""
+    if x.shape != out.shape or x.dtype != out.dtype or x.shape[-1] != x.shape[-2] or not x.is_contiguous():
+        raise HipExtensionError("dihedral: contiguous square rasters of equal shape and dtype expected")
+    B, S = x.shape[0], x.shape[-1]  # noqa: N806
+    planes = x.numel() // (B * S * S)
+    call("mh_dihedral", x, out, flags, _I(B), _L(planes), _I(S), _I(x.element_size()))
+
+
 def colsum(x, out, M, N, ld):
     call("mh_colsum", x, _I(1 if x.dtype == torch.float32 else 0), out, _I(M), _I(N), _I(ld))
 

@@ -141,3 +141,17 @@ def test_checkpoint_round_trip_and_reference_style_keys(tmp_path):
         assert torch.equal(a, b), k
     with pytest.raises(RuntimeError):
         SSLModule.load_from_checkpoint(path, strict=True, datasets=treesat())
+
+
+def test_transform_flag_draws_follow_reference_order():
+    """Host side of the input staging: three ``rng.choice([True, False])`` draws per sample, in the reference's order
+    (maestro/dataset/dataset.py:230-249), packed as bit0 / bit1 / bit2."""
+    import numpy as np
+    from maestro_amd.train.staging import draw_transform_flags
+    from oracle import staging as ost
+    flags = draw_transform_flags(np.random.default_rng(123), 16)
+    rng = np.random.default_rng(123)
+    assert flags.tolist() == [ost.draw_flags(rng) for _ in range(16)]
+    assert draw_transform_flags(np.random.default_rng(0), 4, use_transform=False).tolist() == [0, 0, 0, 0]
+    a = np.arange(24).reshape(1, 2, 3, 4)   # flips only (a transpose needs square rasters)
+    assert np.array_equal(ost.transform_rasters({"r": a}, 3)["r"], a[:, :, ::-1, ::-1])
