@@ -174,6 +174,51 @@ def case_table():
     }
 
 
+def sup_case_table():
+    """Probe / finetune cases: dataset with targets, head type; each runs in both phases."""
+    return {
+        # FLAIR-shaped segmentation on the aerial grid; s2 tokens are bilinearly resized 5x5 -> 4x4 onto it
+        "sup_flair_seg": dict(
+            dataset="flair", ds_kwargs=dict(filter_inputs=["aerial", "s2"], filter_targets=["cosia"], crop_meters=51.2),
+            mods=dict(aerial=dict(image_size=64, patch=16, bands=[[3, 0, 1, 2]], norm_bands=[1, 3], norm_fac=255.0)),
+            size="tiny", model_kw=dict(depth=3), inter_depth=1, fusion="group", type_head="attentive", B=2, seed=31),
+        # TreeSatAI-TS-shaped multilabel classification over all tokens, attentive and mean ("linear") reductions
+        "sup_treesat_mlc": dict(
+            dataset="treesatai_ts", ds_kwargs=dict(filter_targets=["treesat_mlc_thresh"]),
+            mods=dict(aerial=dict(image_size=60, patch=20, bands=4, norm_bands=[1, 3], norm_fac=255.0)),
+            size="tiny", model_kw=dict(depth=3), inter_depth=1, fusion="group", type_head="attentive", B=3, seed=32),
+        "sup_treesat_mean": dict(
+            dataset="treesatai_ts", ds_kwargs=dict(filter_targets=["treesat_mlc_thresh"]),
+            mods=dict(aerial=dict(image_size=60, patch=20, bands=4, norm_bands=[1, 3], norm_fac=255.0)),
+            size="tiny", model_kw=dict(depth=2), inter_depth=0, fusion="mod", type_head="linear", B=3, seed=33),
+        # PASTIS-HD-shaped: two targets at once (segmentation with missing_val = 19 on the s2 grid + multilabel)
+        "sup_pastis_two": dict(
+            dataset="pastis_hd", ds_kwargs=dict(filter_inputs=["s2", "s1_asc"], filter_targets=["pastis_seg", "pastis_mlc"]),
+            mods=dict(), size="tiny", model_kw=dict(depth=2), inter_depth=1, fusion="group", type_head="attentive",
+            B=2, seed=34),
+    }
+
+
+def make_targets(dataset, B: int, seed: int) -> dict:  # noqa: N803
+    """Synthetic targets of the wire format: raster targets int64 [B, 1, 1, H, W] (about 10 % missing_val pixels),
+    multilabel targets float32 [B, C] in {0, 1} (sample 0 carries a missing_val entry), classif int64 [B]."""
+    out = {}
+    for i, (t, c) in enumerate(dataset.targets.items()):
+        g = torch.Generator().manual_seed(777 + 31 * seed + i)
+        if c.type_target == "segment":
+            H = round(dataset.crop_meters / c.resolution_meters)  # noqa: N806
+            y = torch.randint(0, c.num_classes, (B, 1, 1, H, H), generator=g)
+            y[torch.rand(B, 1, 1, H, H, generator=g) < 0.1] = c.missing_val
+        elif c.type_target == "multilabel_classif":
+            y = (torch.rand(B, c.num_classes, generator=g) < 0.3).float()
+            if B > 1:
+                y[0, 1] = c.missing_val
+        else:
+            y = torch.randint(0, c.num_classes, (B,), generator=g)
+        out[t] = y
+    return out
+
+
 def build_datasets(case: dict, ns) -> object:
     """Instantiate a DatasetsConfig from a case with either the reference's or this repo's classes (``ns``)."""
     cls = {"flair": ns.FLAIRConfig, "treesatai_ts": ns.TreeSatAITSConfig, "pastis_hd": ns.PASTISHDConfig,
@@ -209,7 +254,7 @@ def init_weights(model: torch.nn.Module, seed: int) -> float:
         for name, p in sorted(model.state_dict().items()):
             if not p.dtype.is_floating_point:
                 continue
-            if name.endswith("norm.weight") or ".net.0.weight" in name:
+            if name.endswith("norm.weight") or name.endswith("norm_fc.weight") or ".net.0.weight" in name:
                 p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
             elif p.ndim <= 1 or name.endswith("bias"):
                 p.copy_(0.1 * torch.randn(p.shape, generator=g))
@@ -346,6 +391,72 @@ def run_case(name: str, case: dict, ref, ours) -> dict:
     return out
 
 
+def run_sup_case(name: str, case: dict, ref, ours) -> dict:
+    """Reference probe / finetune forward + loss_pred + backward on seeded weights and inputs -> stored vectors."""
+    from collections import defaultdict
+
+    from oracle import heads as oheads
+    from oracle import mae as omae
+
+    ns_ref = SimpleNamespace(
+        FLAIRConfig=ref.flair.FLAIRConfig, TreeSatAITSConfig=ref.ts.TreeSatAITSConfig,
+        PASTISHDConfig=ref.pastis.PASTISHDConfig, S2NAIPConfig=ref.s2.S2NAIPConfig,
+        InputRasterConfig=ref.InputRasterConfig, PatchSizeConfig=ref.PatchSizeConfig,
+        DatasetsConfig=lambda root_dir, name_dataset, **kw: ref.DatasetsConfig(
+            root_dir=root_dir, name_dataset=name_dataset,
+            **{k: kw.get(k, d()) for k, d in dict(
+                treesatai_ts=ref.ts.TreeSatAITSConfig, pastis_hd=ref.pastis.PASTISHDConfig,
+                flair=ref.flair.FLAIRConfig, s2_naip=ref.s2.S2NAIPConfig).items()}))
+    ds_ref, ds_our = build_datasets(case, ns_ref), build_datasets(case, ours)
+    torch.manual_seed(1000 + case["seed"])
+    ssl = ref.model.SSLModule(datasets=ds_ref, mask=ref.MaskConfig(), interpolate="nearest", fusion_mode=case["fusion"],
+                              inter_depth=case["inter_depth"], model="mae", model_size=case["size"],
+                              type_head=case["type_head"], loss="l2_norm", use_ema=False)
+    common = dict(interpolate="nearest", fusion_mode=case["fusion"], inter_depth=case["inter_depth"], model="mae",
+                  num_levels=1, type_head=case["type_head"], fac_abs_enc=1.0, fac_date_enc=1.0)
+    ssl.model = getattr(ref.mae, f"mae_{case['size']}")(datasets=ds_ref, mask=ref.MaskConfig(), **common, **case["model_kw"])
+    oracle = omae.build_oracle(ds_our, ours.MaskConfig(), model_size=case["size"], **common, **case["model_kw"])
+    chk = init_weights(oracle, case["seed"])
+    missing, unexpected = ssl.model.load_state_dict(oracle.state_dict(), strict=True)   # heads included: key-for-key
+    assert not missing and not unexpected
+
+    class _NoMetric:   # the metric updates of compute_loss_pred are logging, not arithmetic of the loss
+        def update(self, *a, **k):
+            pass
+
+    ssl._modules.pop("metrics", None)
+    ssl.metrics = defaultdict(_NoMetric)
+
+    batch = make_batch(ds_our.dataset, case["B"], case["seed"])
+    batch.update(make_targets(ds_our.dataset, case["B"], case["seed"]))
+    out = {"weights_checksum": np.float64(chk)}
+    for phase in ("probe", "finetune"):
+        ssl.trainer = SimpleNamespace(ssl_phase=phase)
+        rb = {k: v.clone() for k, v in batch.items()}
+        rb, _, _, logits = ssl.model(rb, ssl_phase=phase)
+        loss = ssl.compute_loss_pred(rb, logits, stage="train")
+        ssl.model.zero_grad()
+        loss.backward()
+        out[f"{phase}/loss"] = np.float64(loss.item())
+        for k, p in ssl.model.named_parameters():
+            if p.grad is not None:
+                out[f"{phase}/gradnorm/{k}"] = np.float64(p.grad.double().norm().item())
+        for t, lg in logits.items():
+            flat = lg.detach().reshape(lg.shape[0], -1)
+            stride = max(1, flat.shape[1] // 4096)
+            out[f"{phase}/logits/{t}"] = flat[:, ::stride].numpy().astype(np.float32)   # strided sample of every logit map
+            out[f"{phase}/logits_sum/{t}"] = np.float64(lg.detach().double().sum().item())
+        # oracle on the same inputs
+        ob = {k: v.clone() for k, v in batch.items()}
+        ob, _, _, ologits = oracle(ob, phase)
+        oloss = oheads.compute_loss_pred(oracle.dataset, ob, ologits)
+        worst = max(float((logits[t] - ologits[t]).detach().abs().max()) for t in logits)
+        print(f"[{name}/{phase}] loss_ref={loss.item():.8f} loss_oracle={oloss.item():.8f} max|logit diff|={worst:.2e} "
+              f"params with grad={sum(1 for k in out if k.startswith(phase + '/gradnorm/'))}")
+        assert worst < 1e-4 and abs(loss.item() - oloss.item()) < 1e-5
+    return out
+
+
 def layer_vectors(ref) -> dict:
     """Known-answer vectors for the directly importable reference layers (embed.py / utils.py)."""
     out = {}
@@ -389,9 +500,14 @@ def main() -> None:
     ref = import_reference()
     GOLDEN.mkdir(parents=True, exist_ok=True)
     meta = dict(torch=torch.__version__, threads=torch.get_num_threads())
-    np.savez_compressed(GOLDEN / "layers.npz", **layer_vectors(ref))
-    for name, case in case_table().items():
-        out = run_case(name, case, ref, ours)
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"      # all | pretrain | sup
+    if which in ("all", "pretrain"):
+        np.savez_compressed(GOLDEN / "layers.npz", **layer_vectors(ref))
+        for name, case in case_table().items():
+            out = run_case(name, case, ref, ours)
+            np.savez_compressed(GOLDEN / f"{name}.npz", torch_version=np.array(meta["torch"]), **out)
+    for name, case in (sup_case_table().items() if which in ("all", "sup") else ()):
+        out = run_sup_case(name, case, ref, ours)
         np.savez_compressed(GOLDEN / f"{name}.npz", torch_version=np.array(meta["torch"]), **out)
     pyc = [p for p in REFERENCE.rglob("__pycache__")]
     assert not pyc, f"bytecode was written into the reference tree: {pyc}"

@@ -22,6 +22,7 @@ from math import gcd
 import torch
 from torch import Tensor, nn
 
+from oracle.heads import ClassificationHead, PixelifyHead
 from oracle.layers import (
     Patchify,
     Pixelify,
@@ -109,7 +110,19 @@ class OracleMAE(nn.Module):
         # --- mask tokens (mim.py:160-167)
         self.mask_token = nn.ParameterDict(
             {m: nn.Parameter(torch.randn(1, g, 1, 1, decoder_dim)) for m, g in self.len_bands.items()})
-        self.heads = nn.ModuleDict()  # probe/finetune heads: out of scope of the pretrain oracle
+        # --- probe / finetune heads (mim.py:169-197); stride = 2**(num_levels-1) = 1
+        self.heads = nn.ModuleDict()
+        for t, target in ds.targets.items():
+            if hasattr(target, "resolution_meters"):                       # raster target -> PixelifyHead on the ref grid
+                if ds.ref_input is None:
+                    raise ValueError(f"Ref input must be provided for raster target {t}")
+                size = round(ds.crop_meters / target.resolution_meters)
+                ref_grid = self.out_grid_size[ds.ref_input]
+                if size % ref_grid:
+                    raise ValueError(f"Target image size {size} is not a multiple of ref input grid {ref_grid}")
+                self.heads[t] = PixelifyHead(type_head, embed_dim, target.num_classes, size // ref_grid)
+            else:
+                self.heads[t] = ClassificationHead(type_head, embed_dim, target.num_classes)
         # --- masking tables + transformers (mae.py:60-176)
         names, self.mask_ratio, self.mask_mod, self.mask_bands, self.mask_dates, self.mask_loc = mask_tables(
             ds, mask, fusion_mode, self.len_bands)
@@ -207,12 +220,45 @@ class OracleMAE(nn.Module):
         mask_rec.scatter_(1, masked, True)
         return masked, visible, mask_rec
 
+    # ------------------------------------------------------------------ encode / logits
+    def encode(self, x: dict[str, Tensor]) -> dict[str, Tensor]:
+        """mae.py:289-298 + mim.py:396-423: per-group encoders, then the joint encoder on the concatenated groups."""
+        x = {g: self._model_for(self.encoder, g)(t) for g, t in x.items()}
+        if self.encoder_inter is not None:
+            names = list(x)
+            joint = self.encoder_inter(torch.cat([x[g] for g in names], dim=1))
+            for g, part in zip(names, joint.split([x[g].shape[1] for g in names], dim=1)):
+                x[g] = part
+        return x
+
+    def compute_logits(self, x_enc: dict[str, Tensor], ssl_phase: str) -> dict[str, Tensor]:
+        """mim.py:343-394: raster targets see every modality's token grid bilinearly resized to the reference grid and
+        stacked on the date axis; classification targets see all tokens of all modalities."""
+        xm = self._ungroup(x_enc)                                  # per modality [B, D, L, E]
+        ref = self.dataset.ref_input
+        x_ref = None
+        if ref is not None:
+            H = self.out_grid_size[ref]  # noqa: N806
+            parts = []
+            for m, t in xm.items():
+                B, D, L, E = t.shape  # noqa: N806
+                h = self.out_grid_size[m]
+                img = t.reshape(B * D, h, h, E).permute(0, 3, 1, 2)
+                img = torch.nn.functional.interpolate(img, (H, H), mode="bilinear")
+                parts.append(img.permute(0, 2, 3, 1).reshape(B, D, H * H, E))
+            x_ref = torch.cat(parts, dim=1)
+        x_all = torch.cat([t.flatten(1, 2) for t in xm.values()], dim=1)
+        logits = {}
+        for t, target in self.dataset.targets.items():
+            logits[t] = self.heads[t](x_ref if target.type_target == "segment" else x_all, ssl_phase)
+        return logits
+
     # ------------------------------------------------------------------ forward
     def forward(self, batch: dict[str, Tensor], ssl_phase: str = "pretrain", noise: dict | None = None,
                 struct_masks: dict | None = None, return_internals: bool = False):
         """Pretrain forward.  ``noise`` / ``struct_masks`` inject recorded RNG draws (per group)."""
-        if ssl_phase != "pretrain":
-            raise NotImplementedError("oracle covers the pretrain branch only")
+        if ssl_phase not in ("pretrain", "probe", "finetune"):
+            raise ValueError(f"Invalid ssl phase {ssl_phase}")
         batch = self.resize_and_rescale(batch)
         # embed (mim.py:199-230)
         x_mod, tok_mod, dates = {}, {}, {}
@@ -226,6 +272,10 @@ class OracleMAE(nn.Module):
         x, tok = self._group(x_mod), self._group(tok_mod)
         x = self.add_encodings(x, dates, ref_date, self.enc_pos_encoding, self.embed_dim, self.grid_size)
         internals = {"x_embed": {g: t.clone() for g, t in x.items()}}
+        if ssl_phase != "pretrain":       # probe / finetune: unmasked sequences, heads on the encoded tokens
+            x = self.encode(x)
+            logits = self.compute_logits(x, ssl_phase)
+            return (batch, None, None, logits, dict(internals, x_encoded=x)) if return_internals else (batch, None, None, logits)
         # mask (mim.py:276-308, mae.py:178-264)
         if struct_masks is None:
             struct_masks = self.draw_struct_masks({g: t.shape[:2] for g, t in x.items()})
@@ -237,14 +287,7 @@ class OracleMAE(nn.Module):
             bi = torch.arange(B)[:, None]
             x_vis[g] = x[g][bi, visible_idx[g]]
             tok_msk[g] = tok[g][bi, masked_idx[g]]
-        # encode (mae.py:289-298, mim.py:396-423)
-        for g in x_vis:
-            x_vis[g] = self._model_for(self.encoder, g)(x_vis[g])
-        if self.encoder_inter is not None:
-            names = list(x_vis)
-            joint = self.encoder_inter(torch.cat([x_vis[g] for g in names], dim=1))
-            for g, part in zip(names, joint.split([x_vis[g].shape[1] for g in names], dim=1)):
-                x_vis[g] = part
+        x_vis = self.encode(x_vis)
         internals["x_encoded"] = {g: t.clone() for g, t in x_vis.items()}
         # enc->dec, unmask (mae.py:266-287, 300-302)
         x_dec = {}
