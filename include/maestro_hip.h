@@ -184,6 +184,47 @@ int mh_count_masked(const uint8_t* mask, int B, int L, int t_lo, int t_hi, int* 
 int mh_masked_loss(const float* rec, const float* target, const uint8_t* mask_group, const int* n_masked, float weight,
                    float* acc, void* drec, int B, int Lm, int Lgroup, int tok_off, int PPC, int p, void* stream);
 
+/* ---------------------------------------------------------------------------------------------- probe / finetune heads
+ * (maestro/ssl/mim.py:343-394 compute_logits, maestro/layers/head.py, maestro/train/base.py:98-151)
+ *
+ * Bilinear resize of a channel-last token grid onto the reference grid (mim.py:357-366, F.interpolate bilinear,
+ * align_corners=False): rows (b, in_off + d*h*h + y*h + x) of in f32 [B, in_rows, E] -> rows (b, out_off + d*H*H + Y*H + X)
+ * of out f32 [B, out_rows, E].  h == H is an exact copy.  The backward is the transposed map written as a gather
+ * (deterministic); accumulate = 1 adds to din. */
+int mh_token_resize(const float* in, long in_rows, int in_off, float* out, long out_rows, int out_off, int B, int D, int h,
+                    int H, int E, void* stream);
+int mh_token_resize_bwd(const float* dout, long out_rows, int out_off, float* din, long in_rows, int in_off, int B, int D,
+                        int h, int H, int E, int accumulate, void* stream);
+/* AttentiveReduce (head.py:28-62) after its LayerNorm + to_kv GEMM: kv bf16 [rows, 2*dim] (k | v); sequence (b, l),
+ * b < n_batch, l < Lr, runs over t < T at row (b*T + t)*Lr + l  (PixelifyHead: T = dates, Lr = reference-grid tokens;
+ * ClassificationHead: T = all tokens, Lr = 1).  out f32 [n_batch*Lr, dim] = softmax_t(scale * q.k_t) . v per head
+ * (heads = 8, dim in {192, 384, 768, 1024}), lse f32 [n_batch*Lr, 8] kept for the backward.
+ * Backward: dkv bf16 [rows, 2*dim]; dq_partial f32 [mh_attn_reduce_partial_rows(n_batch*Lr), dim], summed with mh_colsum. */
+int mh_attn_reduce_fwd(const void* kv, const float* query, float* out, float* lse, int n_batch, int T, int Lr, int dim,
+                       int heads, void* stream);
+int mh_attn_reduce_bwd(const void* kv, const float* query, const float* out, const float* lse, const float* dout, void* dkv,
+                       float* dq_partial, int n_batch, int T, int Lr, int dim, int heads, void* stream);
+long mh_attn_reduce_partial_rows(int n_seq);
+/* type_head = "linear": mean over the same token axis (head.py:77-78, 111-112); x f32 [rows, dim] -> out f32 [n_batch*Lr, dim]. */
+int mh_mean_reduce_fwd(const float* x, float* out, int n_batch, int T, int Lr, int dim, void* stream);
+int mh_mean_reduce_bwd(const float* dout, float* dx, int n_batch, int T, int Lr, int dim, void* stream);
+/* ClassificationHead.linear (head.py:83,93), fp32: out[b, c] = bias[c] + x[b, :] . W[c, :]; backward ACCUMULATES dW, db
+ * and writes dx (optional). */
+int mh_head_linear_fwd(const float* x, const float* W, const float* bias, float* out, int B, int C, int E, void* stream);
+int mh_head_linear_bwd(const float* x, const float* W, const float* dout, float* dx, float* dW, float* db, int B, int C, int E,
+                       void* stream);
+/* loss_pred (base.py:98-151).  count[0] += #targets != missing_val (target_bytes-wide signed integers).
+ * mh_ce_loss: target raster [B, S, S] (S = g*P; classification: g = P = 1), logits f32 at PATCH layout [B*g*g, P*P*C] with
+ * columns (p1*P + p2)*C + c (PixelifyBands order, embed.py:153-160); acc[0] += mean over valid pixels of cross entropy,
+ * dlogits (bf16 or f32, same layout) = (softmax - onehot) / n_valid, 0 on missing pixels; n_valid = 0 -> loss 0.
+ * mh_bce_loss: logits / target f32 [B, C]; rows with any target == missing_val are skipped (base.py:122-123);
+ * acc[0] += mean BCE-with-logits, dlogits f32 [B, C]. */
+int mh_count_valid(const void* target, int target_bytes, long n, long missing_val, int* count, void* stream);
+int mh_ce_loss(const float* logits, const void* target, int target_bytes, long missing_val, const int* n_valid, float* acc,
+               void* dlogits, int dlogits_is_f32, int B, int g, int P, int C, void* stream);
+int mh_bce_loss(const float* logits, const float* target, float missing_val, float* acc, float* dlogits, int B, int C,
+                void* stream);
+
 /* ---------------------------------------------------------------------------------------------- misc
  * column sums: out[n] += sum_m x[m, n]  (bias gradients); x bf16 or f32; atomically accumulated. */
 int mh_colsum(const void* x, int x_is_f32, float* out, int M, int N, int ld, void* stream);

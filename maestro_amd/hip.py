@@ -266,6 +266,58 @@ def dihedral(x, out, flags):
     call("mh_dihedral", x, out, flags, _I(B), _L(planes), _I(S), _I(x.element_size()))
 
 
+# ---- probe / finetune heads (csrc/heads.hip)
+def token_resize(x, in_rows, in_off, out, out_rows, out_off, B, D, h, H, E):  # noqa: N803
+    call("mh_token_resize", x, _L(in_rows), _I(in_off), out, _L(out_rows), _I(out_off), _I(B), _I(D), _I(h), _I(H), _I(E))
+
+
+def token_resize_bwd(dout, out_rows, out_off, din, in_rows, in_off, B, D, h, H, E, accumulate=False):  # noqa: N803
+    call("mh_token_resize_bwd", dout, _L(out_rows), _I(out_off), din, _L(in_rows), _I(in_off), _I(B), _I(D), _I(h), _I(H),
+         _I(E), _I(int(accumulate)))
+
+
+def attn_reduce_partial_rows(n_seq: int) -> int:
+    lib().mh_attn_reduce_partial_rows.restype = ctypes.c_long
+    return int(lib().mh_attn_reduce_partial_rows(_I(n_seq)))
+
+
+def attn_reduce_fwd(kv, query, out, lse, n_batch, T, Lr, dim, heads=8):  # noqa: N803
+    call("mh_attn_reduce_fwd", kv, query, out, lse, _I(n_batch), _I(T), _I(Lr), _I(dim), _I(heads))
+
+
+def attn_reduce_bwd(kv, query, out, lse, dout, dkv, dq_partial, n_batch, T, Lr, dim, heads=8):  # noqa: N803
+    call("mh_attn_reduce_bwd", kv, query, out, lse, dout, dkv, dq_partial, _I(n_batch), _I(T), _I(Lr), _I(dim), _I(heads))
+
+
+def mean_reduce_fwd(x, out, n_batch, T, Lr, dim):  # noqa: N803
+    call("mh_mean_reduce_fwd", x, out, _I(n_batch), _I(T), _I(Lr), _I(dim))
+
+
+def mean_reduce_bwd(dout, dx, n_batch, T, Lr, dim):  # noqa: N803
+    call("mh_mean_reduce_bwd", dout, dx, _I(n_batch), _I(T), _I(Lr), _I(dim))
+
+
+def head_linear_fwd(x, W, bias, out, B, C, E):  # noqa: N803
+    call("mh_head_linear_fwd", x, W, bias, out, _I(B), _I(C), _I(E))
+
+
+def head_linear_bwd(x, W, dout, dx, dW, db, B, C, E):  # noqa: N803
+    call("mh_head_linear_bwd", x, W, dout, dx, dW, db, _I(B), _I(C), _I(E))
+
+
+def count_valid(target, missing_val, count):
+    call("mh_count_valid", target, _I(target.element_size()), _L(target.numel()), _L(int(missing_val)), count)
+
+
+def ce_loss(logits, target, missing_val, n_valid, acc, dlogits, B, g, P, C):  # noqa: N803
+    call("mh_ce_loss", logits, target, _I(target.element_size()), _L(int(missing_val)), n_valid, acc, dlogits,
+         _I(1 if dlogits.dtype == torch.float32 else 0), _I(B), _I(g), _I(P), _I(C))
+
+
+def bce_loss(logits, target, missing_val, acc, dlogits, B, C):  # noqa: N803
+    call("mh_bce_loss", logits, target, _F(float(missing_val)), acc, dlogits, _I(B), _I(C))
+
+
 def colsum(x, out, M, N, ld):
     call("mh_colsum", x, _I(1 if x.dtype == torch.float32 else 0), out, _I(M), _I(N), _I(ld))
 
