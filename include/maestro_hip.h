@@ -214,14 +214,14 @@ int mh_head_linear_fwd(const float* x, const float* W, const float* bias, float*
 int mh_head_linear_bwd(const float* x, const float* W, const float* dout, float* dx, float* dW, float* db, int B, int C, int E,
                        void* stream);
 /* loss_pred (base.py:98-151).  count[0] += #targets != missing_val (target_bytes-wide signed integers).
- * mh_ce_loss: target raster [B, S, S] (S = g*P; classification: g = P = 1), logits f32 at PATCH layout [B*g*g, P*P*C] with
- * columns (p1*P + p2)*C + c (PixelifyBands order, embed.py:153-160); acc[0] += mean over valid pixels of cross entropy,
+ * mh_ce_loss: target raster [B, S, S] (S = g*P; classification: g = P = 1), logits f32 at PATCH layout [B*g*g, ld >= P*P*C]
+ * with columns (p1*P + p2)*C + c (PixelifyBands order, embed.py:153-160); acc[0] += mean over valid pixels of cross entropy,
  * dlogits (bf16 or f32, same layout) = (softmax - onehot) / n_valid, 0 on missing pixels; n_valid = 0 -> loss 0.
  * mh_bce_loss: logits / target f32 [B, C]; rows with any target == missing_val are skipped (base.py:122-123);
  * acc[0] += mean BCE-with-logits, dlogits f32 [B, C]. */
 int mh_count_valid(const void* target, int target_bytes, long n, long missing_val, int* count, void* stream);
 int mh_ce_loss(const float* logits, const void* target, int target_bytes, long missing_val, const int* n_valid, float* acc,
-               void* dlogits, int dlogits_is_f32, int B, int g, int P, int C, void* stream);
+               void* dlogits, int dlogits_is_f32, int B, int g, int P, int C, int ld, void* stream);
 int mh_bce_loss(const float* logits, const float* target, float missing_val, float* acc, float* dlogits, int B, int C,
                 void* stream);
 

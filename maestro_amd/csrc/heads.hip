@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void count_valid_kernel(const void* __restrict
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const void* __restrict__ target,
                                                       int tbytes, long missing, const int* __restrict__ n_valid,
                                                       float* __restrict__ acc, void* __restrict__ dlogits, int d_is_f32,
-                                                      long n_pix, int g, int P, int C) {
+                                                      long n_pix, int g, int P, int C, int ld) {
     __shared__ float red[4];
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const int nv = *n_valid;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     if (i < n_pix) {
         const int S = g * P;
         const int X = i % S; const long r = i / S; const int Y = r % S; const long b = r / S;
-        const size_t base = ((size_t)(b * g * g + (size_t)(Y / P) * g + X / P) * P * P + (size_t)(Y % P) * P + X % P) * C;
+        const size_t base = (size_t)(b * g * g + (size_t)(Y / P) * g + X / P) * ld + ((size_t)(Y % P) * P + X % P) * C;
         const long t = load_int(target, i, tbytes);
         const bool valid = t != missing && t >= 0 && t < C && nv > 0;
         float m = -INFINITY;
@@ -447,12 +447,13 @@ extern "C" int mh_count_valid(const void* target, int target_bytes, long n, long
 }
 
 extern "C" int mh_ce_loss(const float* logits, const void* target, int target_bytes, long missing_val, const int* n_valid,
-                          float* acc, void* dlogits, int dlogits_is_f32, int B, int g, int P, int C, void* stream) {
-    MH_CHECK_ARG(logits && target && n_valid && acc && dlogits && B > 0 && g > 0 && P > 0 && C > 0, "mh_ce_loss: bad arguments");
+                          float* acc, void* dlogits, int dlogits_is_f32, int B, int g, int P, int C, int ld, void* stream) {
+    MH_CHECK_ARG(logits && target && n_valid && acc && dlogits && B > 0 && g > 0 && P > 0 && C > 0 && ld >= P * P * C,
+                 "mh_ce_loss: bad arguments");
     MH_CHECK_ARG(target_bytes == 1 || target_bytes == 2 || target_bytes == 4 || target_bytes == 8, "mh_ce_loss: target width");
     const long n_pix = (long)B * g * P * g * P;
     hipLaunchKernelGGL(ce_loss_kernel, dim3(ceil_div(n_pix, 256)), dim3(256), 0, (hipStream_t)stream, logits, target, target_bytes,
-                       missing_val, n_valid, acc, dlogits, dlogits_is_f32, n_pix, g, P, C);
+                       missing_val, n_valid, acc, dlogits, dlogits_is_f32, n_pix, g, P, C, ld);
     MH_LAUNCH_CHECK();
     return 0;
 }

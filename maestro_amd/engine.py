@@ -218,8 +218,108 @@ class Stack:
         return cur, cur16
 
 
+class EngineBase:
+    """Launch runtime shared by the step engines: group-parallel HIP streams, hipGraph segments (captured on their second
+    run with unchanged input addresses, eager fallback), gradient-ready spans for the data-parallel hook, GEMM tuning pass."""
+
+    def _init_runtime(self, device, n_side_streams: int) -> None:
+        self.device = device
+        self.grad_hook = None       # callable(lo, hi) invoked when grad[lo:hi] is final (DDP bucket launch)
+        self.use_graphs = True      # capture launch segments into hipGraphs once input addresses repeat
+        self.multi_stream = True    # independent groups on parallel HIP streams
+        self.group_streams = os.environ.get("MAESTRO_GROUP_STREAMS") != "0"   # (only with multi_stream)
+        # MAESTRO_TUNE=1: the first forward / backward run eagerly on one stream with GEMM tile tuning on: every distinct GEMM
+        # signature of the step times the kernel tiles on its own operands once and keeps the fastest (hip.set_gemm_tuning).
+        # Off by default: on C3 the isolated timings pick tiles that are 1 % slower inside the two-stream step than the
+        # library's own rule (1291 vs 1303 tiles/s, same box).
+        self.tune_gemm = os.environ.get("MAESTRO_TUNE", "0") == "1"
+        self._tuned = set()
+        self._graphs, self._seen, self._ready_spans = {}, {}, []
+        self.side_streams = [torch.cuda.Stream(device=device) for _ in range(max(0, n_side_streams))]
+
+    def _grads_ready(self, module) -> None:
+        """Record that the gradient slice of ``module`` is final (handed to ``grad_hook`` after the segment)."""
+        ps = list(module.parameters())
+        if ps:
+            self._ready_spans.append(self.store.span(ps))
+
+    # ------------------------------------------------------------------------------------------ streams / graphs
+    def _run_parallel(self, fns) -> None:
+        if len(fns) == 1 or not self.multi_stream or not self.group_streams:
+            for fn in fns:
+                fn()
+            return
+        main = torch.cuda.current_stream()
+        sides = self.side_streams[: len(fns) - 1]
+        for side in sides:
+            side.wait_stream(main)
+        fns[0]()
+        for side, fn in zip(sides, fns[1:]):
+            with torch.cuda.stream(side):
+                fn()
+        for side in sides:
+            main.wait_stream(side)
+
+    @contextlib.contextmanager
+    def _tuning_pass(self, what: str):
+        if not self.tune_gemm or what in self._tuned or hip.kernel_timer_active():
+            yield
+            return
+        saved = self.multi_stream
+        self.multi_stream = False
+        hip.set_gemm_tuning(True)
+        try:
+            yield
+        finally:
+            hip.set_gemm_tuning(False)
+            self.multi_stream = saved
+            self._tuned.add(what)
+
+    def _segment(self, name: str, key, fn) -> None:
+        """Run one launch segment: eagerly, or as a captured hipGraph replay when the input addresses are unchanged."""
+        if not self.use_graphs or hip.kernel_timer_active():
+            self._ready_spans = []
+            fn()
+            self._flush_ready(self._ready_spans)
+            return
+        entry = self._graphs.get(name)
+        if entry is not None and entry["key"] == key:
+            entry["graph"].replay()
+            self._flush_ready(entry["spans"])
+            return
+        seen = self._seen.get(name, _NEVER)
+        self._ready_spans = []
+        if seen == key:  # second time with the same addresses: capture (the first eager run warmed everything up)
+            graph = torch.cuda.CUDAGraph()
+            try:
+                # thread_local: other threads (e.g. the RCCL watchdog polling events) must not invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    fn()
+            except Exception as exc:  # noqa: BLE001 -- capture is an optimisation: fall back to eager launches
+                import warnings
+                warnings.warn(f"hipGraph capture of segment {name!r} failed ({exc}); continuing with eager launches")
+                self.use_graphs = False
+                torch.cuda.synchronize()
+                self._ready_spans = []
+                fn()
+                self._flush_ready(self._ready_spans)
+                return
+            self._graphs[name] = {"key": key, "graph": graph, "spans": list(self._ready_spans)}
+            graph.replay()
+        else:
+            self._seen[name] = key
+            fn()
+        self._flush_ready(self._ready_spans)
+
+    def _flush_ready(self, spans) -> None:
+        if self.grad_hook is not None:
+            for lo, hi in spans:
+                self.grad_hook(lo, hi)
+
+
+
 # ======================================================================================= the engine
-class MAEEngine:
+class MAEEngine(EngineBase):
     def __init__(self, model, batch_size: int, device, loss: str = "l2_norm") -> None:
         if loss not in ("l1", "l2", "l1_norm", "l2_norm"):
             raise ValueError(f"Invalid loss {loss}.")
@@ -234,10 +334,7 @@ class MAEEngine:
         if m.embed_dim == m.decoder_dim:
             raise NotImplementedError("embed_dim == decoder_dim (Identity enc_to_dec) is not built")
         self.E, self.Dd = m.embed_dim, m.decoder_dim
-        self.grad_hook = None  # callable(lo, hi) invoked when grad[lo:hi] is final (DDP bucket launch)
-        self.use_graphs = True      # capture launch segments into hipGraphs once input addresses repeat
-        self.multi_stream = True    # independent groups on parallel HIP streams
-        self.group_streams = True   # (only with multi_stream) groups on parallel streams
+        self._init_runtime(device, len(model.group_specs) - 1)
         # Weight gradients of the transformer stacks: "fused" = in line with the dgrad chain (split-K, fp32 atomics);
         # "deferred" = one grouped large-tile launch per backward segment (per step without a gradient hook);
         # "auto" = deferred where the launch has enough 256x256 tiles to fill the chip (see _wgrad_plan).
@@ -245,19 +342,9 @@ class MAEEngine:
         if self.wgrad_mode not in ("auto", "fused", "deferred"):
             raise ValueError(f"MAESTRO_WGRAD={self.wgrad_mode!r}: expected auto, fused or deferred")
         self._wgrad_tables, self._wgrad_plans = {}, {}
-        # MAESTRO_TUNE=1: the first forward / backward run eagerly on one stream with GEMM tile tuning on: every distinct GEMM
-        # signature of the step times the kernel tiles on its own operands once and keeps the fastest (hip.set_gemm_tuning).
-        # Off by default: on C3 the isolated timings pick tiles that are 1 % slower inside the two-stream step than the
-        # library's own rule (1291 vs 1303 tiles/s, same box).
-        self.tune_gemm = os.environ.get("MAESTRO_TUNE", "0") == "1"
-        self._tuned = set()
-        if os.environ.get("MAESTRO_GROUP_STREAMS") == "0":
-            self.group_streams = False
-        self._graphs, self._seen, self._ready_spans = {}, {}, []
         self._h2d_done = [None] * RING   # per ring slot: event after the mask uploads that last used it
         self._step = 0
         self._enc_state = {}        # per group: (grad f32, grad bf16) carried between encoder backward segments
-        self.side_streams = [torch.cuda.Stream(device=device) for _ in range(max(0, len(model.group_specs) - 1))]
         B = batch_size  # noqa: N806
         fold = m.fusion_mode in ("shared", "monotemp")
         self.mods, self.groups = m.mod_specs, list(m.group_specs.values())
@@ -341,91 +428,12 @@ class MAEEngine:
             b = self.mb[name]
             hip.pack_rows_bf16(b["pe"].conv.weight, b["w_conv16"], self.E, s.K, s.Kpad)
 
-    def _grads_ready(self, module) -> None:
-        """Record that the gradient slice of ``module`` is final (handed to ``grad_hook`` after the segment)."""
-        ps = list(module.parameters())
-        if ps:
-            self._ready_spans.append(self.store.span(ps))
-
     # ------------------------------------------------------------------------------------------ RNG (host)
     def draw_masks(self, generator=None):
         """Host draws in the reference's order: structural masks first, then ``rand(B, L)`` per group."""
         struct = draw_struct_masks(self.groups, self.mods, generator)
         noise = {g.name: torch.rand((g.Beff, g.L), generator=generator) for g in self.groups}
         return noise, struct
-
-    # ------------------------------------------------------------------------------------------ streams / graphs
-    def _run_parallel(self, fns) -> None:
-        if len(fns) == 1 or not self.multi_stream or not self.group_streams:
-            for fn in fns:
-                fn()
-            return
-        main = torch.cuda.current_stream()
-        sides = self.side_streams[: len(fns) - 1]
-        for side in sides:
-            side.wait_stream(main)
-        fns[0]()
-        for side, fn in zip(sides, fns[1:]):
-            with torch.cuda.stream(side):
-                fn()
-        for side in sides:
-            main.wait_stream(side)
-
-    @contextlib.contextmanager
-    def _tuning_pass(self, what: str):
-        if not self.tune_gemm or what in self._tuned or hip.kernel_timer_active():
-            yield
-            return
-        saved = self.multi_stream
-        self.multi_stream = False
-        hip.set_gemm_tuning(True)
-        try:
-            yield
-        finally:
-            hip.set_gemm_tuning(False)
-            self.multi_stream = saved
-            self._tuned.add(what)
-
-    def _segment(self, name: str, key, fn) -> None:
-        """Run one launch segment: eagerly, or as a captured hipGraph replay when the input addresses are unchanged."""
-        if not self.use_graphs or hip.kernel_timer_active():
-            self._ready_spans = []
-            fn()
-            self._flush_ready(self._ready_spans)
-            return
-        entry = self._graphs.get(name)
-        if entry is not None and entry["key"] == key:
-            entry["graph"].replay()
-            self._flush_ready(entry["spans"])
-            return
-        seen = self._seen.get(name, _NEVER)
-        self._ready_spans = []
-        if seen == key:  # second time with the same addresses: capture (the first eager run warmed everything up)
-            graph = torch.cuda.CUDAGraph()
-            try:
-                # thread_local: other threads (e.g. the RCCL watchdog polling events) must not invalidate the capture
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    fn()
-            except Exception as exc:  # noqa: BLE001 -- capture is an optimisation: fall back to eager launches
-                import warnings
-                warnings.warn(f"hipGraph capture of segment {name!r} failed ({exc}); continuing with eager launches")
-                self.use_graphs = False
-                torch.cuda.synchronize()
-                self._ready_spans = []
-                fn()
-                self._flush_ready(self._ready_spans)
-                return
-            self._graphs[name] = {"key": key, "graph": graph, "spans": list(self._ready_spans)}
-            graph.replay()
-        else:
-            self._seen[name] = key
-            fn()
-        self._flush_ready(self._ready_spans)
-
-    def _flush_ready(self, spans) -> None:
-        if self.grad_hook is not None:
-            for lo, hi in spans:
-                self.grad_hook(lo, hi)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, batch: dict, noise: dict | None = None, struct: dict | None = None) -> torch.Tensor:

@@ -309,9 +309,9 @@ def count_valid(target, missing_val, count):
     call("mh_count_valid", target, _I(target.element_size()), _L(target.numel()), _L(int(missing_val)), count)
 
 
-def ce_loss(logits, target, missing_val, n_valid, acc, dlogits, B, g, P, C):  # noqa: N803
+def ce_loss(logits, target, missing_val, n_valid, acc, dlogits, B, g, P, C, ld=None):  # noqa: N803
     call("mh_ce_loss", logits, target, _I(target.element_size()), _L(int(missing_val)), n_valid, acc, dlogits,
-         _I(1 if dlogits.dtype == torch.float32 else 0), _I(B), _I(g), _I(P), _I(C))
+         _I(1 if dlogits.dtype == torch.float32 else 0), _I(B), _I(g), _I(P), _I(C), _I(P * P * C if ld is None else ld))
 
 
 def bce_loss(logits, target, missing_val, acc, dlogits, B, C):  # noqa: N803

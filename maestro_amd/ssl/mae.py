@@ -19,6 +19,7 @@ from math import gcd
 import torch
 from torch import nn
 
+from maestro_amd.layers.head import ClassificationHead, PixelifyHead
 from maestro_amd.layers.embed import Patchify, Pixelify
 from maestro_amd.layers.utils import pool_pos_table, posemb_sincos_2d
 from maestro_amd.layers.vit import Transformer
@@ -121,7 +122,20 @@ class MAE(nn.Module):
 
         self.mask_token = nn.ParameterDict(
             {m: nn.Parameter(torch.randn(1, lb, 1, 1, decoder_dim)) for m, lb in self.len_bands.items()})
-        self.heads = nn.ModuleDict()  # probe / finetune heads: SURVEY §8(f) "next" row, not on the pretrain path
+        # probe / finetune heads (mim.py:169-197; embed_dim * stride with stride = 1)
+        self.type_head = type_head
+        self.heads = nn.ModuleDict()
+        for t, target in ds.targets.items():
+            if hasattr(target, "resolution_meters"):      # raster target: PixelifyHead on the reference input's grid
+                if ds.ref_input is None:
+                    raise ValueError(f"Ref input must be provided for raster target {t}")
+                target_image_size = round(ds.crop_meters / target.resolution_meters)
+                ref_grid = self.out_grid_size[ds.ref_input]
+                if target_image_size % ref_grid:
+                    raise ValueError(f"Target image size {target_image_size} is not a multiple of ref input grid {ref_grid}")
+                self.heads[t] = PixelifyHead(type_head, embed_dim, target.num_classes, target_image_size // ref_grid)
+            else:
+                self.heads[t] = ClassificationHead(type_head, embed_dim, target.num_classes)
 
         # ---- masking probabilities per fusion mode (mae.py:60-131)
         nd_mod, nd_group = {}, {}
@@ -156,7 +170,7 @@ class MAE(nn.Module):
                                                      self.decoder_mlp_dim) for n in name_models})
         self.encoder_inter = (Transformer(embed_dim, inter_depth, heads, dim_head, self.mlp_dim)
                               if inter_depth else None)
-        self._engine = None
+        self._engine = self._sup_engine = None
         self._build_specs()
 
     # ------------------------------------------------------------------------------------------ geometry
@@ -204,14 +218,31 @@ class MAE(nn.Module):
         device = torch.device(device) if device is not None else next(self.parameters()).device
         if self._engine is None or self._engine.B != batch_size or self._engine.loss != loss \
                 or self._engine.device != device:
+            self._sup_engine = None
             self._engine = MAEEngine(self, batch_size, device, loss=loss)
         return self._engine
 
+    def sup_engine(self, batch_size: int, device=None, phase: str = "finetune"):
+        """The probe / finetune step engine (unmasked encoders + heads + loss_pred).  One engine owns the parameters at a
+        time: building this one re-homes them, so a pretrain engine of the same model is dropped (and vice versa)."""
+        from maestro_amd.engine_sup import SupervisedEngine
+
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        e = self._sup_engine
+        if e is None or e.B != batch_size or e.phase != phase or e.device != device:
+            self._engine = None
+            self._sup_engine = SupervisedEngine(self, batch_size, device, phase=phase)
+        return self._sup_engine
+
     def forward(self, batch: dict, ssl_phase: str = "pretrain"):
-        """Reference contract ``(batch, pixels_rec, mask_rec, logits)``; pretrain branch only."""
-        if ssl_phase != "pretrain":
-            raise NotImplementedError("probe/finetune branch is a SURVEY §8(f) 'next' row; only pretrain is built")
+        """Reference contract ``(batch, pixels_rec, mask_rec, logits)`` (mim.py:473-505)."""
         first = next(iter(self.dataset.inputs))
+        if ssl_phase in ("probe", "finetune"):
+            eng = self.sup_engine(batch[first].shape[0], batch[first].device, ssl_phase)
+            eng.forward(batch)
+            return eng.returned_batch(batch), None, None, eng.logits()
+        if ssl_phase != "pretrain":
+            raise ValueError(f"Invalid ssl phase {ssl_phase}. Expected 'pretrain' or 'probe' or 'finetune'")
         eng = self.engine(batch[first].shape[0], batch[first].device)
         eng.forward(batch)
         pixels_rec, mask_rec = eng.reconstructions()

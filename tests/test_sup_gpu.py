@@ -1,0 +1,97 @@
+"""Probe / finetune branch on the GPU: SupervisedEngine vs the oracle AND the reference's golden
+vectors (tests/golden/sup_*.npz), same weights, inputs and targets.
+
+Tolerances (bf16 GEMMs / attention with fp32 accumulation vs the fp32 CPU oracle):
+  loss_pred ............... |d| <= 2e-2 * |loss|
+  logits .................. relative L2 error <= 3e-2 per target
+  parameter gradients ..... relative L2 error <= 8e-2 per parameter (plus an absolute floor for ~zero grads);
+                            probe: every non-head gradient is exactly zero (features detached, head.py:17-25)
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import maestro_amd.conf as conf
+from maestro_amd.ssl import mae as pmae
+from oracle import heads as oh
+from tests.test_oracle_sup import CASES, build_sup_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a - b).double().norm() / b.double().norm().clamp(min=1e-12)).item()
+
+
+def _setup(name):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    case, ds, oracle, _, batch = build_sup_case(name)
+    model = getattr(pmae, f"mae_{case['size']}")(
+        datasets=ds, mask=conf.MaskConfig(), interpolate="nearest", fusion_mode=case["fusion"], inter_depth=case["inter_depth"],
+        model="mae", num_levels=1, type_head=case["type_head"], fac_abs_enc=1.0, fac_date_enc=1.0, **case["model_kw"])
+    missing, unexpected = model.load_state_dict(oracle.state_dict(), strict=True)   # heads included, key for key
+    assert not missing and not unexpected
+    return dev, case, ds, oracle, model, batch
+
+
+@pytest.mark.parametrize("phase", ["probe", "finetune"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_supervised_engine_matches_oracle_and_reference(golden_dir, name, phase):
+    dev, case, ds, oracle, model, batch = _setup(name)
+    gold = np.load(golden_dir / f"{name}.npz", allow_pickle=False)
+    eng = model.sup_engine(case["B"], dev, phase)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    for it in range(3):          # eager, hipGraph capture, replay: identical results
+        loss = eng.forward(dbatch)
+        eng.zero_grad()
+        eng.backward()
+        torch.cuda.synchronize()
+        if it == 0:
+            first, grad0 = loss.item(), eng.store.grad.clone()
+        else:
+            assert abs(loss.item() - first) <= 1e-5 * abs(first)
+            assert ((eng.store.grad - grad0).norm() / grad0.norm()).item() < 1e-4
+    logits = eng.logits()
+
+    ob, _, _, ologits = oracle({k: v.clone() for k, v in batch.items()}, phase)
+    oloss = oh.compute_loss_pred(oracle.dataset, ob, ologits)
+    oracle.zero_grad()
+    oloss.backward()
+    assert abs(loss.item() - oloss.item()) < 2e-2 * abs(oloss.item()), (loss.item(), oloss.item())
+    assert abs(loss.item() - float(gold[f"{phase}/loss"])) < 2e-2 * abs(float(gold[f"{phase}/loss"]))
+    for t in ologits:
+        assert logits[t].shape == ologits[t].shape
+        assert _rel(logits[t].cpu(), ologits[t].detach()) < 3e-2, (t, _rel(logits[t].cpu(), ologits[t].detach()))
+        flat = logits[t].cpu().reshape(logits[t].shape[0], -1)
+        stride = max(1, flat.shape[1] // 4096)
+        assert _rel(flat[:, ::stride], torch.from_numpy(gold[f"{phase}/logits/{t}"])) < 3e-2   # the reference's own logits
+    ograds = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
+    gmax = max(g.abs().max().item() for g in ograds.values())
+    worst = (0.0, None)
+    for k, p in model.named_parameters():
+        if id(p) not in eng.store.offset:
+            continue
+        got = eng.store.g(p).cpu()
+        if k not in ograds:
+            assert float(got.abs().max()) == 0.0, f"{k}: gradient on a detached / unused parameter"
+            continue
+        want = ograds[k]
+        err, ref = (got - want).double().norm().item(), want.double().norm().item()
+        assert err <= 8e-2 * ref + 1e-5 * gmax * want.numel() ** 0.5, f"{k}: grad rel err {err / max(ref, 1e-12):.3e}"
+        worst = max(worst, (err / max(ref, 1e-12), k))
+        assert abs(got.double().norm().item() - float(gold[f"{phase}/gradnorm/{k}"])) <= 8e-2 * ref + 1e-5 * gmax * want.numel() ** 0.5
+    print(f"[{name}/{phase}] loss hip={loss.item():.6f} oracle={oloss.item():.6f} worst grad rel err {worst}")
+
+
+def test_model_forward_contract_probe(golden_dir):
+    """``MAE.forward(batch, ssl_phase)`` returns ``(batch, None, None, logits)`` in probe / finetune (mim.py:503-505)."""
+    dev, case, ds, oracle, model, batch = _setup("sup_pastis_two")
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    out_batch, rec, msk, logits = model(dbatch, ssl_phase="probe")
+    assert rec is None and msk is None and set(logits) == set(ds.dataset.targets)
+    _, _, _, ologits = oracle({k: v.clone() for k, v in batch.items()}, "probe")
+    for t in logits:
+        assert logits[t].shape == ologits[t].shape and _rel(logits[t].cpu(), ologits[t].detach()) < 3e-2
