@@ -64,14 +64,17 @@ class _EngineLoss(torch.autograd.Function):
         st = eng.store
         if not (isinstance(grad_out, torch.Tensor) and grad_out.numel() == 1 and float(grad_out) == 1.0):
             st.grad.mul_(grad_out.reshape(()))  # e.g. gradient accumulation / loss scaling by the trainer
+        lo, hi = getattr(eng, "trainable_span", (0, st.total))
         for p in st.params:  # re-attach views if the trainer cleared them (zero_grad(set_to_none=True))
-            if p.grad is None or p.grad.data_ptr() != st.g(p).data_ptr():
+            if not lo <= st.offset[id(p)] < hi:
+                p.grad = None   # probe: detached encoder features -> no gradient (the optimizer then skips the parameter)
+            elif p.grad is None or p.grad.data_ptr() != st.g(p).data_ptr():
                 p.grad = st.g(p)
         return None, None, None
 
 
 class SSLModule(_Base):
-    """SSL module (pretrain branch on the MI355X engine)."""
+    """SSL module: pretrain, probe and finetune steps on the MI355X engines."""
 
     def __init__(self, datasets, mask, interpolate, fusion_mode, inter_depth, model, model_size, type_head="attentive",
                  loss="l2_norm", use_date_enc=True, use_ema=False) -> None:
@@ -128,8 +131,8 @@ class SSLModule(_Base):
     def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict: bool = False, datasets=None, **overrides):
         """Counterpart of ``LightningModule.load_from_checkpoint`` as the reference calls it
         (``maestro/run_experiment.py:66-73``: ``strict=False, datasets=datasets``).  Reads reference checkpoints
-        (e.g. the HF ``MAESTRO_*_base`` weights): same keys; ``heads.*`` / ``ema_model.*`` entries that this build does not
-        instantiate are skipped when ``strict=False``."""
+        (e.g. the HF ``MAESTRO_*_base`` weights): same keys, heads included; entries without a counterpart (``ema_model.*``
+        when ``use_ema`` is off, heads of targets that are filtered out) are skipped when ``strict=False``."""
         from maestro_amd.conf import MaskConfig
 
         ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
@@ -202,12 +205,42 @@ class SSLModule(_Base):
         log_inputs, log_preds, log_targets = self.compute_logs_rec(batch, engine, self._ssl_phase(), stage)
         return {"loss": loss, "log_inputs": log_inputs, "log_preds": log_preds, "log_targets": log_targets}
 
+    def compute_loss_pred(self, engine, stage: str) -> torch.Tensor:
+        """``loss_pred`` of the last supervised forward (``base.py:98-151``; computed on the GPU by mh_ce_loss / mh_bce_loss)."""
+        loss = _EngineLoss.apply(self._anchor, engine, engine.loss_acc)
+        self.metrics[f"loss_pred_{stage}"].update(loss)
+        return loss
+
+    def compute_logs_pred(self, batch, engine, ssl_phase: str, stage: str):
+        """Keys as ``base.py:58-96`` for the raster targets; values are built lazily and hold the class maps of sample
+        [0, 0] (the reference renders colour overlays with torchvision, which is logging, not arithmetic)."""
+        log_inputs, log_preds, log_targets = {}, {}, {}
+        for name_target, target in self.dataset.targets.items():
+            if target.type_target != "segment":
+                continue
+            log_inputs[f"{ssl_phase}_{name_target}_{stage}/_input"] = \
+                lambda: batch[self.dataset.log_inputs[0]][0, 0, :3]
+            log_targets[f"{ssl_phase}_{name_target}_{stage}/_target"] = lambda t=name_target: batch[t][0, 0, 0]
+            log_preds[f"{ssl_phase}_{name_target}_{stage}/_pred"] = lambda t=name_target: engine.logits()[t][0, 0].argmax(dim=0)
+        return log_inputs, log_preds, log_targets
+
+    def probe_or_finetune_step(self, batch: dict, stage: str) -> dict:
+        """``base.py:185-224``.  (Evaluating the CPU-resident EMA copy at val/test time is host orchestration: load its
+        state dict into ``self.model`` before evaluating.)"""
+        phase = self._ssl_phase()
+        first = next(iter(self.dataset.inputs))
+        engine = self.model.sup_engine(batch[first].shape[0], batch[first].device, phase)
+        engine.forward(batch)
+        loss = self.compute_loss_pred(engine, stage)
+        log_inputs, log_preds, log_targets = self.compute_logs_pred(batch, engine, phase, stage)
+        return {"loss": loss, "log_inputs": log_inputs, "log_preds": log_preds, "log_targets": log_targets}
+
     def shared_step(self, batch: dict, stage: str) -> dict:
         phase = self._ssl_phase()
         if phase == "pretrain":
             return self.pretrain_step(batch, stage)
         if phase in ("probe", "finetune"):
-            raise NotImplementedError("probe/finetune steps are a SURVEY §8(f) 'next' row")
+            return self.probe_or_finetune_step(batch, stage)
         raise ValueError(f"Invalid ssl phase {phase}. Expected 'pretrain' or 'probe' or 'finetune'")
 
     def training_step(self, batch: dict, batch_idx: int) -> dict:  # noqa: ARG002

@@ -45,15 +45,19 @@ class FusedAdamW:
 
         self.engine, self.lr, self.betas, self.eps, self.wd = engine, lr, betas, eps, weight_decay
         st = engine.store
-        self.m = torch.zeros_like(st.flat)
-        self.v = torch.zeros_like(st.flat)
+        # the engine's trainable slice of the flat buffer (probe phase: the heads only -- frozen parameters must not even
+        # see weight decay, as torch.optim.AdamW skips parameters without a gradient)
+        self.lo, self.hi = getattr(engine, "trainable_span", (0, st.total))
+        self.m = torch.zeros(self.hi - self.lo, dtype=st.flat.dtype, device=st.flat.device)
+        self.v = torch.zeros_like(self.m)
         self.t = 0
 
     def step(self, lr: float | None = None, grad_scale: float = 1.0) -> None:
         st = self.engine.store
         self.t += 1
-        hip.adamw(st.flat, st.grad, self.m, self.v, st.half, st.total, self.lr if lr is None else lr, self.betas[0],
-                  self.betas[1], self.eps, self.wd, self.t, grad_scale)
+        lo, hi = self.lo, self.hi
+        hip.adamw(st.flat[lo:hi], st.grad[lo:hi], self.m, self.v, st.half[lo:hi], hi - lo, self.lr if lr is None else lr,
+                  self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
         st.mark_synced()               # bf16 shadows were refreshed by the kernel itself
         self.engine._pack_conv_weights()  # patch-embed weights live in a K-padded bf16 layout
 

@@ -57,6 +57,36 @@ class PretrainLoop:
         return loss
 
 
+class SupervisedLoop:
+    """Probe / finetune counterpart of :class:`PretrainLoop` (reference ``base.py:185-224`` around the optimizer step):
+    engine forward (+ ``loss_pred``) -> backward (probe: heads only) -> all-reduce -> fused AdamW on the trainable slice."""
+
+    def __init__(self, model, batch_size: int, device, phase: str = "finetune", base_lr: float = 3e-5, betas=(0.9, 0.99),
+                 weight_decay: float = 0.01, total_steps: int = 1000, world_size: int = 1, final_factor: float = 1e7,
+                 bucket_mb: int = 64) -> None:
+        self.engine = model.sup_engine(batch_size, device, phase)
+        lr = scaled_lr(base_lr, batch_size, 1, 1, world_size)
+        self.sched = OneCycle(lr, max(total_steps, 2), pct_start=0.2, div_factor=1000.0,
+                              final_div_factor=final_factor / 1000.0)
+        self.opt = FusedAdamW(self.engine, lr, betas=betas, weight_decay=weight_decay)
+        lo, hi = self.engine.trainable_span
+        self.sync = GradSync(self.engine.store.grad[lo:hi], bucket_bytes=bucket_mb << 20) if world_size > 1 else None
+        self.it = 0
+
+    def step(self, batch: dict) -> torch.Tensor:
+        eng = self.engine
+        loss = eng.forward(batch)
+        eng.zero_grad()
+        eng.backward()
+        scale = 1.0
+        if self.sync is not None:      # one exchange after the backward (the supervised phases are short fine-tuning runs)
+            self.sync.begin()
+            scale = self.sync.finish()
+        self.opt.step(lr=self.sched.lr(self.it), grad_scale=scale)
+        self.it += 1
+        return loss
+
+
 def fit(module, batches, device, steps: int, **kw) -> list[float]:
     """Tiny driver: ``module`` is an :class:`~maestro_amd.train.model.SSLModule`; returns the per-step losses."""
     first = next(iter(module.dataset.inputs))

@@ -128,15 +128,14 @@ def test_checkpoint_round_trip_and_reference_style_keys(tmp_path):
                     inter_depth=3, model="mae", model_size="tiny", loss="l1_norm")
     path = tmp_path / "pretrain-epoch=0.ckpt"
     ckpt = mod.checkpoint()
-    # a reference checkpoint additionally carries heads / ema weights this build does not instantiate
-    ckpt["state_dict"]["model.heads.treesat_mlc_thresh.linear.weight"] = torch.zeros(15, 192)
+    # a reference checkpoint written with use_ema=True additionally carries the EMA copy
+    assert "model.heads.treesat_mlc_thresh.linear.weight" in ckpt["state_dict"]      # heads: same keys as the reference
     ckpt["state_dict"]["ema_model.mask_token.aerial"] = torch.zeros(1, 1, 1, 1, 512)
     torch.save(ckpt, path)
     assert all(k.startswith("model.") for k in mod.checkpoint()["state_dict"])
     new = SSLModule.load_from_checkpoint(path, map_location="cpu", strict=False, datasets=treesat())
     assert new.loss_name == "l1_norm" and new.model.mask_ratio["aerial"] == 0.6 and new.model.inter_depth == 3
-    assert not new.loaded_missing and sorted(new.loaded_unexpected) == [
-        "ema_model.mask_token.aerial", "model.heads.treesat_mlc_thresh.linear.weight"]
+    assert not new.loaded_missing and sorted(new.loaded_unexpected) == ["ema_model.mask_token.aerial"]
     for (k, a), (_, b) in zip(mod.model.state_dict().items(), new.model.state_dict().items()):
         assert torch.equal(a, b), k
     with pytest.raises(RuntimeError):
@@ -155,3 +154,21 @@ def test_transform_flag_draws_follow_reference_order():
     assert draw_transform_flags(np.random.default_rng(0), 4, use_transform=False).tolist() == [0, 0, 0, 0]
     a = np.arange(24).reshape(1, 2, 3, 4)   # flips only (a transpose needs square rasters)
     assert np.array_equal(ost.transform_rasters({"r": a}, 3)["r"], a[:, :, ::-1, ::-1])
+
+
+def test_head_state_dict_keys_match_oracle():
+    """Probe / finetune heads: the holder tree has the reference's keys and shapes (the oracle's tree was loaded
+    strict=True into the real reference in oracle/gen_golden.py:run_sup_case)."""
+    import maestro_amd.conf as conf
+    from maestro_amd.ssl import mae as pmae
+    from oracle import mae as om
+    from oracle.gen_golden import build_datasets, sup_case_table
+    for name, case in sup_case_table().items():
+        ds = build_datasets(case, conf)
+        kw = dict(interpolate="nearest", fusion_mode=case["fusion"], inter_depth=case["inter_depth"], model="mae",
+                  num_levels=1, type_head=case["type_head"], fac_abs_enc=1.0, fac_date_enc=1.0, **case["model_kw"])
+        ours = getattr(pmae, f"mae_{case['size']}")(datasets=ds, mask=conf.MaskConfig(), **kw).state_dict()
+        ref = om.build_oracle(ds, conf.MaskConfig(), model_size=case["size"], **kw).state_dict()
+        assert set(ours) == set(ref), (name, set(ours) ^ set(ref))
+        assert all(ours[k].shape == ref[k].shape for k in ref), name
+        assert any(k.startswith("heads.") for k in ref)

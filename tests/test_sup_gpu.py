@@ -95,3 +95,42 @@ def test_model_forward_contract_probe(golden_dir):
     _, _, _, ologits = oracle({k: v.clone() for k, v in batch.items()}, "probe")
     for t in logits:
         assert logits[t].shape == ologits[t].shape and _rel(logits[t].cpu(), ologits[t].detach()) < 3e-2
+
+
+@pytest.mark.parametrize("phase", ["probe", "finetune"])
+def test_ssl_module_supervised_step_and_loop(phase):
+    """Lightning-style step (``loss.backward()`` fills ``param.grad``; probe leaves the encoder without gradients) and the
+    built-in loop: the loss of a fixed batch goes down, and probe does not move a single encoder weight."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from types import SimpleNamespace
+
+    from maestro_amd.train.model import SSLModule
+    from maestro_amd.train.trainer import SupervisedLoop
+    from oracle.gen_golden import build_datasets, make_batch, make_targets
+    dev = torch.device("cuda:0")
+    case = CASES["sup_treesat_mlc"]
+    ds = build_datasets(case, conf)
+    torch.manual_seed(0)
+    module = SSLModule(datasets=ds, mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=1,
+                       model="mae", model_size="tiny", type_head="attentive", loss="l2_norm")
+    module.trainer = SimpleNamespace(ssl_phase=phase)
+    batch = make_batch(ds.dataset, 4, 1)
+    batch.update(make_targets(ds.dataset, 4, 1))
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    out = module.training_step(batch, 0)
+    assert set(out) == {"loss", "log_inputs", "log_preds", "log_targets"} and out["loss"].requires_grad
+    out["loss"].backward()
+    named = dict(module.model.named_parameters())
+    assert all(named[k].grad is not None and float(named[k].grad.abs().sum()) > 0 for k in named if k.startswith("heads."))
+    enc = [k for k in named if k.startswith("encoder.")]
+    if phase == "probe":
+        assert all(named[k].grad is None for k in enc)
+    else:
+        assert all(named[k].grad is not None for k in enc)
+    before = {k: named[k].detach().clone() for k in enc[:4]}
+    loop = SupervisedLoop(module.model, 4, dev, phase=phase, base_lr=3e-3, total_steps=40)
+    losses = [float(loop.step(batch)) for _ in range(25)]
+    assert losses[-1] < 0.8 * losses[0], losses
+    moved = [float((named[k].detach() - before[k]).abs().max()) for k in before]
+    assert (max(moved) == 0.0) if phase == "probe" else (min(moved) > 0.0)
