@@ -38,13 +38,66 @@ WORKLOADS = {
     "c5": dict(desc="ViT-B MAE, S2-NAIP-urban (aerial, spot, s2, s1), bf16 path", size="medium", gflop_tile=301.3,
                ds=lambda: conf.DatasetsConfig(name_dataset="s2_naip", s2_naip=conf.S2NAIPConfig())),
 }
+# probe / finetune workloads (`--phase probe|finetune`): same inputs, with the dataset's target
+SUP_WORKLOADS = {
+    "c3": dict(desc="ViT-B, FLAIR-HUB-shaped aerial + Sentinel-2, semantic segmentation (cosia, 15 classes, 512x512)", size="medium",
+               ds=lambda: conf.DatasetsConfig(name_dataset="flair", flair=conf.FLAIRConfig(filter_inputs=["aerial", "s2"], filter_targets=["cosia"]))),
+    "c4": dict(desc="ViT-L, TreeSatAI-TS (aerial, s2, s1_asc, s1_des), multilabel classification (15 labels)", size="large",
+               ds=lambda: conf.DatasetsConfig(name_dataset="treesatai_ts", treesatai_ts=conf.TreeSatAITSConfig())),
+}
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def build_model(workload: str):
+def sup_gflop_per_tile(model, phase: str) -> float:
+    """Algorithmic GFLOP per tile of a probe / finetune step (GEMM + attention matmuls, SURVEY §8d formula on the FULL
+    sequences; finetune = 3 x forward, probe = forward + 2 x heads)."""
+    t = next(iter(model.encoder.values()))
+    E, M, I = model.embed_dim, model.mlp_dim, t.heads * t.dim_head  # noqa: N806, E741
+
+    def stack(n_tok, depth):
+        return depth * (6 * n_tok * E * I + 4 * n_tok * n_tok * I + 2 * n_tok * I * E + 4 * n_tok * E * M)
+
+    groups = list(model.group_specs.values())
+    enc = sum(stack(g.L, model.depth - model.inter_depth) for g in groups)
+    enc += stack(sum(g.L for g in groups), model.inter_depth) if model.inter_depth else 0
+    enc += sum(2 * s.n_tok * s.K * E for s in model.mod_specs.values())
+    heads = 0.0
+    ds = model.dataset
+    for t, c in ds.targets.items():
+        head = model.heads[t]
+        if c.type_target == "segment":
+            G = model.out_grid_size[ds.ref_input]  # noqa: N806
+            rows, n = sum(s.D for s in model.mod_specs.values()) * G * G, G * G
+            heads += 2 * n * E * head.patch_size ** 2 * c.num_classes
+        else:
+            rows, n = sum(g.L for g in groups), 1
+            heads += 2 * E * c.num_classes
+        if hasattr(head, "reduce"):
+            heads += 2 * rows * E * 2 * E + 4 * rows * E
+    return ((3 * (enc + heads)) if phase == "finetune" else (enc + 3 * heads)) / 1e9
+
+
+def synthetic_targets(dataset, B: int, device, seed: int = 0) -> dict:  # noqa: N803
+    """Deterministic targets of the wire format: rasters int64 [B, 1, 1, H, W] with ~10 % missing_val, multilabel f32 [B, C]."""
+    out = {}
+    for i, (t, c) in enumerate(dataset.targets.items()):
+        g = torch.Generator().manual_seed(4321 + i + 1000 * seed)
+        if c.type_target == "segment":
+            H = round(dataset.crop_meters / c.resolution_meters)  # noqa: N806
+            y = torch.randint(0, c.num_classes, (B, 1, 1, H, H), generator=g)
+            y[torch.rand(B, 1, 1, H, H, generator=g) < 0.1] = c.missing_val
+        elif c.type_target == "multilabel_classif":
+            y = (torch.rand(B, c.num_classes, generator=g) < 0.3).float()
+        else:
+            y = torch.randint(0, c.num_classes, (B,), generator=g)
+        out[t] = y.to(device)
+    return out
+
+
+def build_model(workload: str, phase: str = "pretrain"):
     from maestro_amd.ssl import mae as pmae
 
-    w = WORKLOADS[workload]
+    w = (WORKLOADS if phase == "pretrain" else SUP_WORKLOADS)[workload]
     ds = w["ds"]()
     model = getattr(pmae, f"mae_{w['size']}")(datasets=ds, mask=conf.MaskConfig(), interpolate="nearest",
                                               fusion_mode="group", inter_depth=3, model="mae", num_levels=1)
@@ -60,12 +113,13 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline_worker(workload: str, seconds: float) -> dict:
+def cpu_baseline_worker(workload: str, seconds: float, phase: str = "pretrain") -> dict:
     """The oracle (CPU restatement = kind "port") timed on this node's host cores on a bounded sample."""
     from maestro_amd.train.trainer import synthetic_batch
+    from oracle import heads as oh
     from oracle import mae as om
 
-    w = WORKLOADS[workload]
+    w = (WORKLOADS if phase == "pretrain" else SUP_WORKLOADS)[workload]
     ds = w["ds"]()
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -76,11 +130,16 @@ def cpu_baseline_worker(workload: str, seconds: float) -> dict:
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.99), weight_decay=0.01)
     B = 2  # noqa: N806
     batch = synthetic_batch(ds.dataset, B, "cpu")
+    batch.update(synthetic_targets(ds.dataset, B, "cpu"))
     times = []
     t_end = time.time() + seconds
     for i in range(50):
         t0 = time.time()
-        loss, _, _ = om.oracle_step(model, batch, "l2_norm")
+        if phase == "pretrain":
+            loss, _, _ = om.oracle_step(model, batch, "l2_norm")
+        else:
+            ob, _, _, logits = model({k: v.clone() for k, v in batch.items()}, phase)
+            loss = oh.compute_loss_pred(model.dataset, ob, logits)
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -92,16 +151,17 @@ def cpu_baseline_worker(workload: str, seconds: float) -> dict:
     times.sort()
     med = times[len(times) // 2]
     return {"value": round(B / med, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} timed steps (after 1 warm-up) of the same {workload} workload at B={B}, fp32, "
+            "sample": f"{len(times)} timed steps (after 1 warm-up) of the same {workload} {phase} workload at B={B}, fp32, "
                       f"torch CPU threads={cores}, forward+loss+backward+AdamW, median step {med:.2f} s"}
 
 
-def cpu_baseline(workload: str, seconds: float) -> dict:
+def cpu_baseline(workload: str, seconds: float, phase: str = "pretrain") -> dict:
     """Run the CPU leg in a child process with a hard wall-clock cap so the default bench always finishes in minutes."""
     import subprocess
 
     cap = 6 * seconds + 60
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", workload, "--cpu-seconds", str(seconds)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", workload, "--cpu-seconds", str(seconds),
+           "--phase", phase]
     env = dict(os.environ, OMP_NUM_THREADS=str(host_cores()), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=cap, env=env)
@@ -123,6 +183,8 @@ def main() -> None:
     ap.add_argument("--config", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU (reference default, conf/opt.py:20)")
     ap.add_argument("--loss", default="l2_norm")
+    ap.add_argument("--phase", default="pretrain", choices=["pretrain", "probe", "finetune"],
+                    help="pretrain = the BASELINE metric; probe / finetune = the supervised branch (configs c3, c4)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -131,12 +193,14 @@ def main() -> None:
     ap.add_argument("--shapes", action="store_true", help="print per-shape kernel times to stderr (diagnostic)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline_worker(args.config, args.cpu_seconds)), flush=True)
+        print(json.dumps(cpu_baseline_worker(args.config, args.cpu_seconds, args.phase)), flush=True)
         return
+    if args.phase != "pretrain" and args.config not in SUP_WORKLOADS:
+        raise SystemExit(f"--phase {args.phase}: choose --config from {sorted(SUP_WORKLOADS)}")
 
     import torch.distributed as dist
     from maestro_amd import hip
-    from maestro_amd.train.trainer import PretrainLoop, synthetic_batch
+    from maestro_amd.train.trainer import PretrainLoop, SupervisedLoop, synthetic_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -159,9 +223,13 @@ def main() -> None:
 
     torch.set_num_threads(min(4, host_cores()))   # host-side torch ops are tiny (mask draws); a 128-thread pool only adds latency
     torch.manual_seed(42 + rank)
-    ds, model = build_model(args.config)
-    loop = PretrainLoop(model, args.batch, dev, loss=args.loss, total_steps=args.steps + args.warmup, world_size=world)
+    ds, model = build_model(args.config, args.phase)
+    if args.phase == "pretrain":
+        loop = PretrainLoop(model, args.batch, dev, loss=args.loss, total_steps=args.steps + args.warmup, world_size=world)
+    else:
+        loop = SupervisedLoop(model, args.batch, dev, phase=args.phase, total_steps=args.steps + args.warmup, world_size=world)
     batch = synthetic_batch(ds.dataset, args.batch, dev, seed=rank)
+    batch.update(synthetic_targets(ds.dataset, args.batch, dev, seed=rank))
     if args.single_stream:
         loop.engine.multi_stream = False
 
@@ -199,13 +267,16 @@ def main() -> None:
     if rank == 0:
         tiles = args.batch * world * args.steps
         value = tiles / elapsed
-        w = WORKLOADS[args.config]
+        w = dict((WORKLOADS if args.phase == "pretrain" else SUP_WORKLOADS)[args.config])
+        if args.phase != "pretrain":
+            w["gflop_tile"] = round(sup_gflop_per_tile(model, args.phase), 1)
         out = {
-            "metric": "MAE-pretrain tiles/sec", "value": round(value, 2), "unit": "tiles/s", "n_gpus": world,
+            "metric": f"MAE-{args.phase} tiles/sec", "value": round(value, 2), "unit": "tiles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: {w['desc']}", "tiles_per_gpu": args.batch,
-                       "global_batch": args.batch * world, "loss": args.loss, "fusion_mode": "group", "inter_depth": 3,
+                       "global_batch": args.batch * world, "loss": args.loss if args.phase == "pretrain" else "loss_pred",
+                       "fusion_mode": "group", "inter_depth": 3,
                        "parallelism": f"dp{world}", "params_M": round(loop.engine.store.total / 1e6, 1),
                        "final_loss": round(loss_val, 5), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3)},
             "whole_step": {"train_gflop_per_tile": w["gflop_tile"],
@@ -214,7 +285,7 @@ def main() -> None:
         if timer is not None:
             out["roofline"] = timer.roofline(MFMA_PEAK_TFLOPS)
             traffic_file = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-            if os.path.exists(traffic_file):  # PMC passes are separate runs (rocprofv3 --pmc); committed summary
+            if os.path.exists(traffic_file) and args.phase == "pretrain":  # PMC passes are separate runs (rocprofv3 --pmc); committed summary
                 kern = json.load(open(traffic_file))["kernels"].get(out["roofline"]["kernel"])
                 if kern:
                     out["roofline"]["traffic"] = kern["hbm_bytes_per_launch"]
@@ -225,7 +296,7 @@ def main() -> None:
             for ms, kind, shape, n, tf in timer.by_shape(args.steps)[:40]:
                 print(f"{ms:8.3f} ms/step {kind:18s} {str(shape):26s} x{n:3d}/step {tf:7.1f} TFLOP/s", file=sys.stderr)
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds, args.phase)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
