@@ -141,6 +141,9 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
         for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR, T::BN>(tb, wn + 16 * j);
 #pragma unroll
         for (int i = 0; i < 8; ++i) fa[i] = read_frag<A_KMAJOR, T::BM>(ta, wm + 16 * i);
+        // keep all 24 fragment reads of the K step in flight before the first MFMA issues (left alone, the scheduler
+        // interleaves them two fragments at a time to save registers and every group of 4 MFMAs then waits on LDS: +2 %)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
