@@ -136,7 +136,8 @@ int mh_embed_finish_bwd(const float* dxg, const float* y, const float* stats, co
 int mh_date_features(const int16_t* dates, const int16_t* ref_date, float* out, int B, int D, int rows, int row_off,
                      float fac, void* stream);
 /* Input staging: resize rasters to image_size (maestro/ssl/mim.py:427-432, F.interpolate with align_corners=False).
- * in f32 [planes, Hin, Win] -> out f32 [planes, Hout, Wout]; mode 0 nearest, 1 bilinear (PyTorch index maps). */
+ * in f32 [planes, Hin, Win] -> out f32 [planes, Hout, Wout]; mode 0 nearest, 1 bilinear, 2 bicubic (PyTorch index maps,
+ * cubic convolution with A = -0.75). */
 int mh_resize(const float* in, float* out, long planes, int Hin, int Win, int Hout, int Wout, int mode, void* stream);
 /* Input staging: per-sample flips / transpose of square rasters (maestro/dataset/dataset.py:224-257: np.flip axis 2, np.flip
  * axis 3, np.swapaxes(2, 3) of the per-sample [D, C, H, W] array, applied in that order).  in/out [B, planes, S, S] of

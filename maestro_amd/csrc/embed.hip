@@ -247,7 +247,17 @@ __global__ __launch_bounds__(256) void rescale_elev_kernel(const float* __restri
 }
 
 // ---- raster resize to image_size (maestro/ssl/mim.py:427-432 -> F.interpolate, align_corners=False): PyTorch's index maps
-// mode 0 nearest: src = min(floor(dst * in/out), in-1); mode 1 bilinear: src = max((dst+0.5)*in/out - 0.5, 0)
+// mode 0 nearest: src = min(floor(dst * in/out), in-1); mode 1 bilinear: src = max((dst+0.5)*in/out - 0.5, 0);
+// mode 2 bicubic: src = (dst+0.5)*in/out - 0.5 (not clamped), 4x4 taps at floor(src)-1..+2 clamped to the image, cubic
+// convolution weights with A = -0.75 (PyTorch's upsample_bicubic2d)
+__device__ __forceinline__ void cubic_weights(float t, float (&w)[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x3 = 2.f - t, x2 = 1.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
 __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ in, float* __restrict__ out, int Hin, int Win,
                                                      int Hout, int Wout, int mode, long total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -258,6 +268,24 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
     if (mode == 0) {
         const int yy = min((int)floorf(y * sy), Hin - 1), xx = min((int)floorf(x * sx), Win - 1);
         out[i] = src[(long)yy * Win + xx];
+        return;
+    }
+    if (mode == 2) {
+        const float ry = sy * (y + 0.5f) - 0.5f, rx = sx * (x + 0.5f) - 0.5f;
+        const int iy = (int)floorf(ry), ix = (int)floorf(rx);
+        float wy[4], wx[4];
+        cubic_weights(ry - iy, wy);
+        cubic_weights(rx - ix, wx);
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int yy = min(max(iy - 1 + a, 0), Hin - 1);
+            float row = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) row += wx[b] * src[(long)yy * Win + min(max(ix - 1 + b, 0), Win - 1)];
+            acc += wy[a] * row;
+        }
+        out[i] = acc;
         return;
     }
     const float fy = fmaxf(sy * (y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sx * (x + 0.5f) - 0.5f, 0.f);
@@ -303,7 +331,7 @@ __global__ __launch_bounds__(256) void dihedral_kernel(const T* __restrict__ in,
 
 extern "C" int mh_resize(const float* in, float* out, long planes, int Hin, int Win, int Hout, int Wout, int mode, void* stream) {
     MH_CHECK_ARG(in && out && in != out && planes > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "mh_resize: bad arguments");
-    MH_CHECK_ARG(mode == 0 || mode == 1, "mh_resize: mode %d (0 nearest, 1 bilinear; bicubic is not built)", mode);
+    MH_CHECK_ARG(mode >= 0 && mode <= 2, "mh_resize: mode %d (0 nearest, 1 bilinear, 2 bicubic)", mode);
     const long total = planes * Hout * Wout;
     hipLaunchKernelGGL(resize_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, Hin, Win, Hout, Wout,
                        mode, total);

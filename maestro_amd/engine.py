@@ -468,9 +468,9 @@ class MAEEngine(EngineBase):
                 raise ValueError(f"batch[{s.name!r}] must be a contiguous float32 GPU tensor")
             if tuple(img.shape[-2:]) != (s.S, s.S) or self.model.interpolate != "nearest":
                 # input staging (mim.py:427-432): resize to image_size on the GPU into an engine-owned buffer
-                mode = {"nearest": 0, "bilinear": 1}.get(self.model.interpolate)
+                mode = {"nearest": 0, "bilinear": 1, "bicubic": 2}.get(self.model.interpolate)
                 if mode is None:
-                    raise NotImplementedError(f"interpolate={self.model.interpolate!r} is not built (nearest, bilinear)")
+                    raise ValueError(f"Invalid interpolate mode {self.model.interpolate!r} (nearest, bilinear, bicubic)")
                 buf = self.mb[s.name].get("resized")
                 if buf is None:
                     buf = self.mb[s.name]["resized"] = torch.empty(self.B, s.Dates, s.C, s.S, s.S, dtype=F32, device=self.device)

@@ -187,7 +187,7 @@ def test_date_features_and_rescale(dev):
     assert torch.equal(res.cpu(), ref_img)
 
 
-@pytest.mark.parametrize("mode,name", [(0, "nearest"), (1, "bilinear")])
+@pytest.mark.parametrize("mode,name", [(0, "nearest"), (1, "bilinear"), (2, "bicubic")])
 @pytest.mark.parametrize("hin,hout", [(32, 64), (64, 64), (100, 60), (6, 10), (37, 128)])
 def test_resize_matches_torch_interpolate(dev, mode, name, hin, hout):
     from maestro_amd import hip
@@ -198,7 +198,7 @@ def test_resize_matches_torch_interpolate(dev, mode, name, hin, hout):
     if mode == 0:
         assert torch.equal(out.cpu(), want)
     else:
-        assert (out.cpu() - want).abs().max() < 2e-6
+        assert (out.cpu() - want).abs().max() < (2e-6 if mode == 1 else 5e-6)
 
 
 def test_depatchify(dev):

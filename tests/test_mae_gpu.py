@@ -166,7 +166,7 @@ def test_graph_replay_and_streams_match_eager(golden_dir, wgrad):
     assert set(eng._graphs) >= {"forward"} | {f"{seg}:{plan}:n" for seg in ("bwd_dec", "bwd_joint", "bwd_enc0")}
 
 
-@pytest.mark.parametrize("interpolate", ["nearest", "bilinear"])
+@pytest.mark.parametrize("interpolate", ["nearest", "bilinear", "bicubic"])
 def test_input_resize_staging_matches_oracle(golden_dir, interpolate):
     """Rasters arriving at another resolution are resized on the GPU (mim.py:427-432) exactly like the oracle/reference."""
     dev, case, gold, ds, oracle, model, batch, noise, struct = _setup("c3_aerial_s2", golden_dir)
