@@ -62,3 +62,22 @@ class GradSync:
             w.wait()
         self.works = []
         return 1.0 / self.world
+
+    def finish_split(self):
+        """Like ``finish`` but does not wait for the LAST bucket (the head of the flat buffer, which backward completes
+        last and which therefore cannot overlap any compute): returns ``(scale, split, wait_tail)`` -- everything in
+        ``[split, numel)`` is reduced; ``[0, split)`` is reduced once ``wait_tail()`` has been called.  The caller runs the
+        optimizer on the upper part first, so the exposed all-reduce hides under it."""
+        split = self.frontier
+        self._launch(0, self.frontier)
+        self.frontier = 0
+        tail = self.works.pop() if (self.works and split > 0) else None
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+        def wait_tail():
+            if tail is not None:
+                tail.wait()
+
+        return 1.0 / self.world, (split if tail is not None else 0), wait_tail

@@ -52,12 +52,20 @@ class FusedAdamW:
         self.v = torch.zeros_like(self.m)
         self.t = 0
 
-    def step(self, lr: float | None = None, grad_scale: float = 1.0) -> None:
+    def step(self, lr: float | None = None, grad_scale: float = 1.0, split: int = 0, between=None) -> None:
+        """``split`` / ``between``: update ``[split, hi)`` first, call ``between()`` (e.g. wait for the last gradient bucket),
+        then update ``[lo, split)`` -- the data-parallel loop hides its exposed all-reduce under the first launch."""
         st = self.engine.store
         self.t += 1
+        lr = self.lr if lr is None else lr
         lo, hi = self.lo, self.hi
-        hip.adamw(st.flat[lo:hi], st.grad[lo:hi], self.m, self.v, st.half[lo:hi], hi - lo, self.lr if lr is None else lr,
-                  self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
+        split = min(max(split, lo), hi) // 4 * 4
+        for a, b in ((split, hi), (lo, split)):
+            if a == lo and between is not None:
+                between()
+            if b > a:
+                hip.adamw(st.flat[a:b], st.grad[a:b], self.m[a - lo: b - lo], self.v[a - lo: b - lo], st.half[a:b], b - a, lr,
+                          self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
         st.mark_synced()               # bf16 shadows were refreshed by the kernel itself
         self.engine._pack_conv_weights()  # patch-embed weights live in a K-padded bf16 layout
 

@@ -50,9 +50,11 @@ class PretrainLoop:
         if self.sync is not None:
             self.sync.begin()
         eng.backward()
-        if self.sync is not None:
-            scale = self.sync.finish()
-        self.opt.step(lr=self.sched.lr(self.it), grad_scale=scale)
+        if self.sync is not None:   # the last bucket (encoder head + patch embed) is reduced under the first AdamW launch
+            scale, split, wait_tail = self.sync.finish_split()
+            self.opt.step(lr=self.sched.lr(self.it), grad_scale=scale, split=split, between=wait_tail)
+        else:
+            self.opt.step(lr=self.sched.lr(self.it), grad_scale=scale)
         self.it += 1
         return loss
 
