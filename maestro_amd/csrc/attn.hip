@@ -165,22 +165,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             }
             float mx = m[qt];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-                mx = fmaxf(fmaxf(mx, fmaxf(s[qt][kt][0], s[qt][kt][1])), fmaxf(s[qt][kt][2], s[qt][kt][3]));
+            for (int kt = 0; kt < 4; ++kt) {   // two v_max3_f32 per four scores
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qt][kt][0]), s[qt][kt][1]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qt][kt][2]), s[qt][kt][3]);
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float alpha = exp2_fast((m[qt] - mx) * c);  // first tile: exp2(-inf) = 0
             m[qt] = mx;
             const float mc = mx * c;
-            float ps = 0.f;
+            // the softmax is VALU-bound (D = 32: ~4 VALU cycles per MFMA cycle): whole-vector expressions so that the
+            // scale / shift and the row sum become packed v_pk_fma_f32 / v_pk_add_f32 (two floats per instruction)
+            const f32x4 c4 = {c, c, c, c}, mc4 = {mc, mc, mc, mc};
+            f32x4 ps4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = exp2_fast(fmaf(s[qt][kt][r], c, -mc));
-                    s[qt][kt][r] = pv;
-                    ps += pv;
-                }
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 t = s[qt][kt] * c4 - mc4;
+                const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
+                s[qt][kt] = pv;
+                ps4 += pv;
+            }
+            const float ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
             lsum[qt] = lsum[qt] * alpha + ps;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
@@ -310,18 +315,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                     dp[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qt][ks], dp[qt][kt], 0, 0, 0);
                 }
             }
-        const bool tail = kv0 + 64 > N;
+        if (kv0 + 64 > N) {   // last KV tile only: keys >= N get probability exp2(-inf) = 0
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kv0 + 16 * kt + 4 * g + r >= N) s[qt][kt][r] = -INFINITY;
+        }
         bf16x8 dsf[2][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
+            const f32x4 c4 = {c, c, c, c}, l4 = {lse2[qt], lse2[qt], lse2[qt], lse2[qt]};
+            const f32x4 d4 = {dlt[qt], dlt[qt], dlt[qt], dlt[qt]};
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float pv = exp2_fast(s[qt][kt][r] * c - lse2[qt]);
-                    if (tail && kv0 + 16 * kt + 4 * g + r >= N) pv = 0.f;
-                    s[qt][kt][r] = pv * (dp[qt][kt][r] - dlt[qt]);  // dS / scale; the factor is applied to dQ once at the end
-                }
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 t = s[qt][kt] * c4 - l4;
+                const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
+                s[qt][kt] = pv * (dp[qt][kt] - d4);  // dS / scale; the factor is applied to dQ once at the end
+            }
             dsf[qt][0] = pack_acc(s[qt][0], s[qt][1]);
             dsf[qt][1] = pack_acc(s[qt][2], s[qt][3]);
         }
@@ -430,14 +443,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         for (int qt = 0; qt < 4; ++qt) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dlt + 16 * qt + 4 * g);
+            const f32x4 c4 = {c, c, c, c};
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = exp2_fast(s[qt][kt][r] * c - l4[r]);  // query >= N: lse2 = +inf -> 0
-                    s[qt][kt][r] = pv;
-                    dp[qt][kt][r] = pv * (dp[qt][kt][r] - d4[r]);  // dS / scale (applied to dK at the end)
-                }
+            for (int kt = 0; kt < 2; ++kt) {
+                const f32x4 t = s[qt][kt] * c4 - l4;                   // query >= N: lse2 = +inf -> probability 0
+                const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
+                s[qt][kt] = pv;
+                dp[qt][kt] = pv * (dp[qt][kt] - d4);                   // dS / scale (applied to dK at the end)
+            }
         }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)

@@ -32,8 +32,10 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even; NaN
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(bf16_t, b);
 }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {   // ONE v_cvt_pk_bf16_f32 (round-to-nearest-even)
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
 // ----------------------------------------------------------------------------- wave / block reductions
