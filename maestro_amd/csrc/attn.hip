@@ -10,6 +10,7 @@
 // "transpose image" read by ds_read_b64_tr_b16 (hardware transpose), both XOR-swizzled to be bank-conflict free.
 #include "common.hpp"
 #include "../../include/maestro_hip.h"
+#include <type_traits>
 
 namespace {
 
@@ -127,7 +128,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     u32x4 rk[2], rv[2];
     tile_load<D>(kb, rs, 0, N, rk);
     tile_load<D>(vb, rs, 0, N, rv);
-    for (int it = 0; it < ntile; ++it) {
+    // The KV loop is peeled: full tiles run a body without any key masking; only the last, partial tile (N % 64 != 0) pays
+    // for the compares and selects (if-converted, they cost ~20 % of the VALU-bound loop when left in the common body).
+    auto kv_tile = [&](int it, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         const int kv0 = it * 64;
         __syncthreads();  // previous tile fully consumed
         tile_store_row<D>(k_img, rk);
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             tile_load<D>(kb, rs, kv0 + 64, N, rk);
             tile_load<D>(vb, rs, kv0 + 64, N, rv);
         }
-        if (q0 >= N) continue;  // wave has no valid query: only helps staging
+        if (q0 >= N) return;  // wave has no valid query: only helps staging
         f32x4 s[2][4];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
@@ -151,12 +155,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
             }
-        const bool tail = kv0 + 64 > N;
         bf16x8 pf[2][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             // running max on the RAW scores (scale > 0 commutes with max); scale and max folded into one FMA per element
-            if (tail) {
+            if constexpr (TAIL) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -200,7 +203,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][u], o[qt][dt], 0, 0, 0);
             }
-    }
+    };
+    const int nfull = N / 64;
+    for (int it = 0; it < nfull; ++it) kv_tile(it, std::false_type{});
+    if (nfull < ntile) kv_tile(nfull, std::true_type{});
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + 16 * qt + lq;
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     u32x4 rk[2], rv[2];
     tile_load<D>(kb, rs, 0, N, rk);
     tile_load<D>(vb, rs, 0, N, rv);
-    for (int it = 0; it < ntile; ++it) {
+    auto kv_tile = [&](int it, auto tail_tag) {   // peeled like the forward: only the partial last tile masks keys
+        constexpr bool TAIL = decltype(tail_tag)::value;
         const int kv0 = it * 64;
         __syncthreads();
         tile_store_row<D>(k_row, rk);
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             tile_load<D>(kb, rs, kv0 + 64, N, rk);
             tile_load<D>(vb, rs, kv0 + 64, N, rv);
         }
-        if (q0 >= N) continue;
+        if (q0 >= N) return;
         f32x4 s[2][4], dp[2][4];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                     dp[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qt][ks], dp[qt][kt], 0, 0, 0);
                 }
             }
-        if (kv0 + 64 > N) {   // last KV tile only: keys >= N get probability exp2(-inf) = 0
+        if constexpr (TAIL) {   // last KV tile only: keys >= N get probability exp2(-inf) = 0
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -328,12 +335,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const f32x4 c4 = {c, c, c, c}, l4 = {lse2[qt], lse2[qt], lse2[qt], lse2[qt]};
-            const f32x4 d4 = {dlt[qt], dlt[qt], dlt[qt], dlt[qt]};
+            const f32x4 nd4 = {-dlt[qt], -dlt[qt], -dlt[qt], -dlt[qt]};
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const f32x4 t = s[qt][kt] * c4 - l4;
                 const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
-                s[qt][kt] = pv * (dp[qt][kt] - d4);  // dS / scale; the factor is applied to dQ once at the end
+                s[qt][kt] = pv * (dp[qt][kt] + nd4);  // dS / scale; the factor is applied to dQ once at the end
             }
             dsf[qt][0] = pack_acc(s[qt][0], s[qt][1]);
             dsf[qt][1] = pack_acc(s[qt][2], s[qt][3]);
@@ -346,7 +353,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) dq[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, dsf[qt][u], dq[qt][dt], 0, 0, 0);
             }
-    }
+    };
+    const int nfull = N / 64;
+    for (int it = 0; it < nfull; ++it) kv_tile(it, std::false_type{});
+    if (nfull < ntile) kv_tile(nfull, std::true_type{});
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + 16 * qt + lq;
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         if (threadIdx.x < 64) {
             const int q = q0 + threadIdx.x;
             s_lse[threadIdx.x] = q < N ? lse[((size_t)b * H + h) * N + q] * LOG2E : INFINITY;
-            s_dlt[threadIdx.x] = q < N ? delta[((size_t)b * H + h) * N + q] : 0.f;
+            s_dlt[threadIdx.x] = q < N ? -delta[((size_t)b * H + h) * N + q] : 0.f;   // negated: dP - delta as a packed add
         }
         __syncthreads();
         if (it + 1 < ntile) {
@@ -442,14 +452,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dlt + 16 * qt + 4 * g);
+            const f32x4 nd4 = *reinterpret_cast<const f32x4*>(s_dlt + 16 * qt + 4 * g);
             const f32x4 c4 = {c, c, c, c};
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 const f32x4 t = s[qt][kt] * c4 - l4;                   // query >= N: lse2 = +inf -> probability 0
                 const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
                 s[qt][kt] = pv;
-                dp[qt][kt] = pv * (dp[qt][kt] - d4);                   // dS / scale (applied to dK at the end)
+                dp[qt][kt] = pv * (dp[qt][kt] + nd4);                  // dS / scale (applied to dK at the end)
             }
         }
 #pragma unroll
