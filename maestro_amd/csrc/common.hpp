@@ -79,6 +79,39 @@ __device__ __forceinline__ void gelu_cdf_pdf(float x, float& cdf, float& pdf) {
     cdf = 0.5f * (1.f + copysignf(erf_abs, x));
     pdf = 0.3989422804014327f * e;
 }
+// Four elements at once, written as whole-vector expressions so that the polynomial, the products and the affine steps
+// compile to packed v_pk_fma_f32 / v_pk_mul_f32 (two floats per instruction); only |x|, rcp, exp2 and the sign transfer stay
+// per element.  Same formula and rounding as gelu_cdf_pdf (the GEMM epilogues are VALU-bound at K = 768: a 64 x 64 wave
+// tile holds 64 outputs per lane against ~6100 MFMA cycles of main loop).
+__device__ __forceinline__ void gelu_cdf_pdf4(const f32x4 x, f32x4& cdf, f32x4& pdf) {
+    const f32x4 ax = {fabsf(x[0]) * 0.70710678118654752f, fabsf(x[1]) * 0.70710678118654752f,
+                      fabsf(x[2]) * 0.70710678118654752f, fabsf(x[3]) * 0.70710678118654752f};
+    const f32x4 den = ax * 0.3275911f + 1.f;
+    const f32x4 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1]), __builtin_amdgcn_rcpf(den[2]),
+                     __builtin_amdgcn_rcpf(den[3])};
+    const f32x4 a = (ax * -1.4426950408889634f) * ax;
+    const f32x4 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1]), __builtin_amdgcn_exp2f(a[2]),
+                     __builtin_amdgcn_exp2f(a[3])};
+    f32x4 poly = t * 1.061405429f - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const f32x4 erf_abs = 1.f - (poly * t) * e;
+    const f32x4 erf = {copysignf(erf_abs[0], x[0]), copysignf(erf_abs[1], x[1]), copysignf(erf_abs[2], x[2]),
+                       copysignf(erf_abs[3], x[3])};
+    cdf = erf * 0.5f + 0.5f;
+    pdf = e * 0.3989422804014327f;
+}
+__device__ __forceinline__ f32x4 gelu_erf4(const f32x4 x) {
+    f32x4 cdf, pdf;
+    gelu_cdf_pdf4(x, cdf, pdf);
+    return x * cdf;
+}
+__device__ __forceinline__ f32x4 gelu_erf_grad4(const f32x4 x) {
+    f32x4 cdf, pdf;
+    gelu_cdf_pdf4(x, cdf, pdf);
+    return x * pdf + cdf;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
     float cdf, pdf;
     gelu_cdf_pdf(x, cdf, pdf);
