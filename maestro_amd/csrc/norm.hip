@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         prow[c] = red[c] + red[3 * dim + c] + red[6 * dim + c] + red[9 * dim + c];
 }
 
-constexpr int RED_ROWS = 32;
+constexpr int RED_ROWS = 8;   // 8 partial rows per thread: short dependent-free load chains, 4x more (cheap) atomics
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int dim,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ dcol) {
