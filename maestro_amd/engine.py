@@ -167,7 +167,7 @@ class Stack:
                     (s["dqkv"], s["h1"], ps.g(attn.to_qkv.weight), 3 * inner, dim, M, 3 * inner, dim, dim)]
         return out
 
-    def backward(self, dx_out: torch.Tensor, hi: int | None = None, lo: int = 0, defer: bool = False):
+    def backward(self, dx_out: torch.Tensor, hi: int | None = None, lo: int = 0, defer: bool = False, ready: bool = True):
         """``dx_out`` (f32; its bf16 copy must already be in ``saved[hi-1]["gy16"]``, see ``top16``): gradient w.r.t. the
         output of layer ``hi - 1`` (default ``x_last``).  Processes layers ``hi-1 .. lo`` and returns ``(grad f32, grad bf16)``
         w.r.t. the input of layer ``lo`` (``x0`` when ``lo == 0``); a range lets the engine cut the backward into several
@@ -176,6 +176,7 @@ class Stack:
         ``defer=False``: the four weight-gradient GEMMs of a layer are issued in line (split-K, fp32 atomics).
         ``defer=True``: only the dgrad chain runs; the caller launches ``wgrad_problems(lo, hi)`` later as one grouped GEMM
         (plain stores: the grouped launch must be the only writer of those weight-gradient slots in the step).
+        ``ready=False``: do not report the layers' gradient slices as final (the caller does, after its grouped launch).
         """
         eng, ps, M = self.eng, self.eng.store, self.M  # noqa: N806
         dim, mlp, inner = self.dim, self.mlp, self.inner
@@ -214,7 +215,8 @@ class Stack:
             hip.layernorm_bwd(self.dh2, M, 0, x_in, M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid, nxt, nxt16,
                               ps.g(attn.norm.weight), ps.g(attn.norm.bias), prev_fc2_bias, self.ln_ws, 1, M, dim)
             cur, cur16 = nxt, nxt16
-            eng._grads_ready(self.t.layers[l])
+            if ready:
+                eng._grads_ready(self.t.layers[l])
         return cur, cur16
 
 
@@ -572,8 +574,9 @@ class MAEEngine(EngineBase):
 
     def _wgrad_plan(self) -> str:
         """"fused" | "all" (every stack deferred into ONE launch at the end of the backward; only without a gradient hook,
-        because every weight gradient then completes last) | "enc" (data parallel: the group encoders' chunks are
-        deferred per segment, so finished slices still overlap the all-reduce; joint / decoder stay fused)."""
+        because every weight gradient then completes last) | "enc" (data parallel: one grouped launch per encoder
+        segment, so finished slices still overlap the all-reduce; the decoder / joint weight gradients -- 324-384 tiles, too
+        few for a launch of their own -- ride along with the first encoder segment's launch and are reported ready there)."""
         if self.wgrad_mode == "fused":
             return "fused"
         hooked = self.grad_hook is not None
@@ -663,7 +666,7 @@ class MAEEngine(EngineBase):
                                       None, dx, dx16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(), gbuf["ln_ws"],
                                       s.Beff, s.n_tok, Dd)
                     self._grads_ready(m.embed_to_rec[s.embed])
-                dx0, _ = st.backward(dx, defer=self._plan == "all")
+                dx0, _ = st.backward(dx, defer=self._plan in ("all", "enc"), ready=self._plan != "enc")
                 self._grads_ready(nrm)
                 # unmask backward: visible rows -> enc_to_dec output grad; masked rows -> mask-token grads
                 hip.gather_rows(dx0, gbuf["vis"], gbuf["dy_e2d"], g.Beff, g.L, g.N, Dd, g.N, 0)
@@ -690,7 +693,7 @@ class MAEEngine(EngineBase):
 
     def _bwd_joint(self) -> None:
         jt = self.joint
-        self._djoint, _ = jt.backward(jt.dxa, defer=self._plan == "all")
+        self._djoint, _ = jt.backward(jt.dxa, defer=self._plan in ("all", "enc"), ready=self._plan != "enc")
         self._grads_ready(jt.t.norm)
 
     def _bwd_encoder_side(self, hi: int, lo: int, first: bool, last: bool) -> None:
@@ -737,8 +740,13 @@ class MAEEngine(EngineBase):
             return run
 
         self._run_parallel([side(g) for g in self.groups])
-        if self._plan == "enc":      # this segment's layers of every group encoder
-            self._launch_wgrads([(st, min(lo, st.depth), min(hi, st.depth)) for st in self.enc.values()])
+        if self._plan == "enc":      # this segment's layers of every group encoder (+ decoder / joint with the first one)
+            items = [(st, min(lo, st.depth), min(hi, st.depth)) for st in self.enc.values()]
+            late = (list(self.dec.values()) + ([self.joint] if self.joint is not None else [])) if first else []
+            self._launch_wgrads(items + [(st, 0, st.depth) for st in late])
+            for st in late:
+                for layer in st.t.layers:
+                    self._grads_ready(layer)
         elif self._plan == "all" and last:
             self._launch_wgrads([(st, 0, st.depth) for st in self._all_stacks()])
         if last:
