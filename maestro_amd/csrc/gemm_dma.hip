@@ -20,13 +20,14 @@ namespace {
 
 constexpr int BK = 32;
 
-// Tile configuration: WM x WN waves, each owning a 128 (M) x 64 (N) accumulator block; S ring stages.
+// Tile configuration: WM x WN waves, each owning a (16 MT) x 64 accumulator block (MT = 8: 128 x 64, MT = 4: 64 x 64); S ring stages.
 //   <2,4,4> 256x256, 512 threads, 128 KiB ring (1 workgroup / CU)      <2,2,3> 256x128 and <1,4,3> 128x256, 256 threads,
 //   72 KiB ring (2 / CU)      <1,2,4> 128x128, 128 threads, 64 KiB ring (2 / CU)
-template <int WM_, int WN_, int S_>
+//   <2,2,4,4> 128x128 with four 64x64 waves (the register-staged kernel's geometry, DMA-fed), 64 KiB ring (2 / CU)
+template <int WM_, int WN_, int S_, int MT_ = 8>
 struct Tile {
-    static constexpr int WM = WM_, WN = WN_, S = S_;
-    static constexpr int BM = 128 * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
+    static constexpr int WM = WM_, WN = WN_, S = S_, MT = MT_;
+    static constexpr int BM = 16 * MT * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;   // 1-KiB DMA pieces per wave and K step
     static constexpr int LDS_BYTES = S * STAGE_BYTES;
@@ -94,7 +95,8 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
     const int nk = (kend - kbeg + BK - 1) / BK;
 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
-    const int wm = (w / T::WN) * 128, wn = (w % T::WN) * 64;
+    constexpr int MT = T::MT;
+    const int wm = (w / T::WN) * (16 * MT), wn = (w % T::WN) * 64;
 
     const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, (short)0, (int)p.b_bytes, 0x00020000);
@@ -118,11 +120,11 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
                                                      b_off0 + t * b_step, 0, 0);
     };
 
-    f32x4 acc[4][8];  // [j (n tile)][i (m tile)]
+    f32x4 acc[4][MT];  // [j (n tile)][i (m tile)]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int t = 0; t < S - 1 && t < nk; ++t) issue(t);
 
@@ -136,16 +138,16 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
         if (t + S - 1 < nk) issue(t + S - 1);   // refill the slot step t-1 just vacated
         const unsigned char* ta = smem + (t % S) * T::STAGE_BYTES;
         const unsigned char* tb = ta + T::A_BYTES;
-        bf16x8 fa[8], fb[4];
+        bf16x8 fa[MT], fb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR, T::BN>(tb, wn + 16 * j);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = read_frag<A_KMAJOR, T::BM>(ta, wm + 16 * i);
+        for (int i = 0; i < MT; ++i) fa[i] = read_frag<A_KMAJOR, T::BM>(ta, wm + 16 * i);
         // keep all 24 fragment reads of the K step in flight before the first MFMA issues (left alone, the scheduler
         // interleaves them two fragments at a time to save registers and every group of 4 MFMAs then waits on LDS: +2 %)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
@@ -153,8 +155,8 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
     __builtin_amdgcn_s_barrier();   // all reads of the ring are done: reuse it as epilogue staging
 
     float* st = reinterpret_cast<float*>(smem) + w * (32 * 68);
-    if (p.flags & MH_GEMM_ATOMIC) gemm_epilogue_atomic<8>(p, acc, st, m0 + wm, n0 + wn);
-    else gemm_epilogue_store<8>(p, acc, st, m0 + wm, n0 + wn);
+    if (p.flags & MH_GEMM_ATOMIC) gemm_epilogue_atomic<MT>(p, acc, st, m0 + wm, n0 + wn);
+    else gemm_epilogue_store<MT>(p, acc, st, m0 + wm, n0 + wn);
 }
 
 template <class T, bool A_KMAJOR, bool B_KMAJOR>
@@ -175,7 +177,8 @@ __global__ __launch_bounds__(T::NT) void gemm_dma_kernel(GemmParams p) {
 typedef Tile<2, 4, 4> T256;      // 256 x 256
 typedef Tile<2, 2, 3> T256x128;  // 256 x 128
 typedef Tile<1, 4, 3> T128x256;  // 128 x 256
-typedef Tile<1, 2, 4> T128;      // 128 x 128
+typedef Tile<1, 2, 4> T128;      // 128 x 128, two 128 x 64 waves
+typedef Tile<2, 2, 4, 4> T128q;  // 128 x 128, four 64 x 64 waves
 
 // Grouped weight-gradient launch: ONE grid over the 256x256 tiles of many independent TN problems
 // (dW_i[M_i, N_i] = dY_i^T X_i, K_i = tokens), no split-K.  Workgroup b (placed on XCD b % 8 by the hardware) runs entry
@@ -261,6 +264,7 @@ int gemm_dma_dispatch(int tile, int layout, int M, int N, int K, const void* A, 
         case MH_TILE_DMA_256x128: rc = launch_dma<T256x128>(layout, p, s); break;
         case MH_TILE_DMA_128x256: rc = launch_dma<T128x256>(layout, p, s); break;
         case MH_TILE_DMA_128: rc = launch_dma<T128>(layout, p, s); break;
+        case MH_TILE_DMA_128x4: rc = launch_dma<T128q>(layout, p, s); break;
         default: return -2;
     }
     if (rc) return rc;

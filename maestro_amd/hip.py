@@ -59,12 +59,12 @@ _I, _F, _L = ctypes.c_int, ctypes.c_float, ctypes.c_long
 
 
 # ---- GEMM: kernel / tile choice (include/maestro_hip.h MH_TILE_*)
-TILE_AUTO, TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128 = -1, 0, 1, 2, 3, 4
-TILES = (TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128)
+TILE_AUTO, TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128, TILE_DMA_128x4 = -1, 0, 1, 2, 3, 4, 5
+TILES = (TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128, TILE_DMA_128x4)
 _LAYOUT_NAME = {0: "NT", 1: "NN", 2: "TN"}
 _TILE_NAME = {TILE_REG_128: "gemm_kernel<{}>", TILE_DMA_256: "gemm_dma_kernel<256x256,{}>",
               TILE_DMA_256x128: "gemm_dma_kernel<256x128,{}>", TILE_DMA_128x256: "gemm_dma_kernel<128x256,{}>",
-              TILE_DMA_128: "gemm_dma_kernel<128x128,{}>"}
+              TILE_DMA_128: "gemm_dma_kernel<128x128,{}>", TILE_DMA_128x4: "gemm_dma_kernel<128x128q,{}>"}
 _tile_choice: dict = {}     # (layout, M, N, K, flags) -> fastest tile, filled while tuning is on
 _tuning = False
 

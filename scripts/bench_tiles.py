@@ -5,7 +5,7 @@ from maestro_amd import hip
 dev = torch.device("cuda:0")
 rows = {"enc_aerial": (8192, 768, 3072, 768), "enc_s2": (3200, 768, 3072, 768), "joint": (11392, 768, 3072, 768),
         "dec_aerial": (32768, 512, 3072, 512), "dec_s2": (12800, 512, 3072, 512)}
-names = {0: "reg128", 1: "d256", 2: "d256x128", 3: "d128x256", 4: "d128"}
+names = {0: "reg128", 1: "d256", 2: "d256x128", 3: "d128x256", 4: "d128", 5: "d128q"}
 tot = {t: 0.0 for t in names}; best_tot = 0.0
 for tag, (M, dim, mlp, inner) in rows.items():
     for lay, lname in ((0, "NT"), (1, "NN")):

@@ -7,7 +7,7 @@ import torch
 from tests.test_gemm_gpu import _dev, _operands
 
 pytestmark = pytest.mark.gpu
-DMA_TILES = [1, 2, 3, 4]   # MH_TILE_DMA_256, _256x128, _128x256, _128
+DMA_TILES = [1, 2, 3, 4, 5]   # MH_TILE_DMA_256, _256x128, _128x256, _128, _128x4
 
 
 @pytest.mark.parametrize("tile", DMA_TILES)
