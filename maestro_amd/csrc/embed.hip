@@ -31,15 +31,31 @@ __global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restric
     const int PP = P * P, K = Ctot * PP;
     float* red = patch + K;
     const float* base = img + ((size_t)bd * Ctot) * S * S + (size_t)(ph * P) * S + pw * P;
-    for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
-        float v = 0.f;
-        if (k < K) {
-            const int c = k / PP, r = k - c * PP, p1 = r / P, p2 = r - p1 * P;
-            v = base[(size_t)c * S * S + p1 * S + p2];
-            if (rescale_elev && c >= 1) v = 30.f * (base[p1 * S + p2] - v);
-            patch[r * Ctot + c] = v;
+    if ((P & 3) == 0 && (Kpad & 3) == 0) {
+        // four consecutive pixels of one patch row per thread: 16-byte image loads, 8-byte bf16 stores
+        for (int k = threadIdx.x * 4; k < Kpad; k += blockDim.x * 4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < K) {
+                const int c = k / PP, r = k - c * PP, p1 = r / P, p2 = r - p1 * P;
+                v = *reinterpret_cast<const f32x4*>(base + (size_t)c * S * S + p1 * S + p2);
+                if (rescale_elev && c >= 1) v = 30.f * (*reinterpret_cast<const f32x4*>(base + p1 * S + p2) - v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) patch[(r + e) * Ctot + c] = v[e];
+            }
+            u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(cols + (size_t)tok * Kpad + k) = pk;
         }
-        cols[(size_t)tok * Kpad + k] = f2bf(v);
+    } else {
+        for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
+            float v = 0.f;
+            if (k < K) {
+                const int c = k / PP, r = k - c * PP, p1 = r / P, p2 = r - p1 * P;
+                v = base[(size_t)c * S * S + p1 * S + p2];
+                if (rescale_elev && c >= 1) v = 30.f * (base[p1 * S + p2] - v);
+                patch[r * Ctot + c] = v;
+            }
+            cols[(size_t)tok * Kpad + k] = f2bf(v);
+        }
     }
     if (!target) return;
     __syncthreads();
@@ -48,24 +64,28 @@ __global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restric
         for (int e = threadIdx.x; e < K; e += blockDim.x) out[e] = patch[e];
         return;
     }
-    // patch-group-wise statistics: unbiased variance, eps 1e-6 (reference model.py:226-229), two-pass
+    // patch-group-wise statistics: unbiased variance, eps 1e-6 (reference model.py:226-229), two-pass; a thread owns whole
+    // pixels of the group (no per-element div / mod)
     int c_lo = 0;
     for (int gi = 0; gi < n_groups; ++gi) {
         const int cg = norm_bands[gi], n = cg * PP;
         float s = 0.f;
-        for (int e = threadIdx.x; e < n; e += blockDim.x) s += patch[(e / cg) * Ctot + c_lo + (e % cg)];
+        for (int pix = threadIdx.x; pix < PP; pix += blockDim.x)
+            for (int cc = 0; cc < cg; ++cc) s += patch[pix * Ctot + c_lo + cc];
         const float mu = block_sum_any(s, red) / n;
         float q = 0.f;
-        for (int e = threadIdx.x; e < n; e += blockDim.x) {
-            const float d = patch[(e / cg) * Ctot + c_lo + (e % cg)] - mu;
-            q += d * d;
-        }
+        for (int pix = threadIdx.x; pix < PP; pix += blockDim.x)
+            for (int cc = 0; cc < cg; ++cc) {
+                const float d = patch[pix * Ctot + c_lo + cc] - mu;
+                q += d * d;
+            }
         const float var = block_sum_any(q, red) / (n - 1);
         const float inv = 1.f / sqrtf(var + 1.0e-6f);
-        for (int e = threadIdx.x; e < n; e += blockDim.x) {
-            const int idx = (e / cg) * Ctot + c_lo + (e % cg);
-            out[idx] = (patch[idx] - mu) * inv;
-        }
+        for (int pix = threadIdx.x; pix < PP; pix += blockDim.x)
+            for (int cc = 0; cc < cg; ++cc) {
+                const int idx = pix * Ctot + c_lo + cc;
+                out[idx] = (patch[idx] - mu) * inv;
+            }
         c_lo += cg;
     }
 }

@@ -5,21 +5,21 @@
 
 namespace {
 
-// One block per sample.  rank_i = #{j : n_j < n_i} + #{j < i : n_j == n_i}  (stable ascending order);
+// One 1024-thread block per sample (the O(L^2) rank is the start of the forward's critical path: 16 waves, not 4).  rank_i = #{j : n_j < n_i} + #{j < i : n_j == n_i}  (stable ascending order);
 // masked <=> rank < k.  Positions inside the visible / masked lists are exclusive prefix counts (ascending index).
-__global__ __launch_bounds__(256) void mask_select_kernel(const float* __restrict__ noise, const uint8_t* __restrict__ smask,
+__global__ __launch_bounds__(1024) void mask_select_kernel(const float* __restrict__ noise, const uint8_t* __restrict__ smask,
                                                           int* __restrict__ visible_idx, int* __restrict__ masked_idx,
                                                           int* __restrict__ inv, uint8_t* __restrict__ mask, int L, int k) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // noise[L] then flags[L] (as int)
     int* flag = reinterpret_cast<int*>(sm + L);
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < L; i += 256) {
+    for (int i = threadIdx.x; i < L; i += 1024) {
         float v = noise[(size_t)b * L + i];
         if (smask && smask[(size_t)b * L + i]) v = 0.f;  // noise *= 1 - struct  (mae.py:240)
         sm[i] = v;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < L; i += 256) {
+    for (int i = threadIdx.x; i < L; i += 1024) {
         const float v = sm[i];
         int r = 0;
         for (int j = 0; j < L; ++j) {
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void mask_select_kernel(const float* __restric
         flag[i] = r < k;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < L; i += 256) {
+    for (int i = threadIdx.x; i < L; i += 1024) {
         int nm = 0;
         for (int j = 0; j < i; ++j) nm += flag[j];
         const int f = flag[i];
@@ -129,7 +129,7 @@ extern "C" int mh_mask_select(const float* noise, const uint8_t* struct_mask, in
                               uint8_t* mask, int B, int L, int k, void* stream) {
     MH_CHECK_ARG(noise && visible_idx && masked_idx && inv && mask, "mh_mask_select: null pointer");
     MH_CHECK_ARG(B > 0 && L > 0 && k >= 0 && k <= L && L <= 8192, "mh_mask_select: bad sizes B=%d L=%d k=%d", B, L, k);
-    hipLaunchKernelGGL(mask_select_kernel, dim3(B), dim3(256), (size_t)L * 8, (hipStream_t)stream, noise, struct_mask,
+    hipLaunchKernelGGL(mask_select_kernel, dim3(B), dim3(1024), (size_t)L * 8, (hipStream_t)stream, noise, struct_mask,
                        visible_idx, masked_idx, inv, mask, L, k);
     MH_LAUNCH_CHECK();
     return 0;
