@@ -237,7 +237,33 @@ class EngineBase:
         self.tune_gemm = os.environ.get("MAESTRO_TUNE", "0") == "1"
         self._tuned = set()
         self._graphs, self._seen, self._ready_spans = {}, {}, []
+        self._inputs = {}           # per batch key: last device address, or the engine-owned staging copy
         self.side_streams = [torch.cuda.Stream(device=device) for _ in range(max(0, n_side_streams))]
+
+    def _stable_inputs(self, batch: dict) -> dict:
+        """The captured launch segments bake device addresses in.  A tensor that keeps its address from step to step (a
+        resident batch) is used in place; one that arrives at a new address (a data loader, ``BatchStager``) is copied into
+        an engine-owned buffer from then on (one D2D copy per step), so the graphs keep replaying instead of being
+        re-captured or falling back to eager launches."""
+        out = {}
+        for k, t in batch.items():
+            if not isinstance(t, torch.Tensor) or not t.is_cuda:
+                out[k] = t
+                continue
+            st = self._inputs.get(k)
+            if st is None:
+                self._inputs[k] = {"ptr": t.data_ptr(), "buf": None}
+                out[k] = t
+            elif st["buf"] is None and st["ptr"] == t.data_ptr():
+                out[k] = t
+            else:
+                buf = st["buf"]
+                if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                    buf = st["buf"] = torch.empty_like(t, memory_format=torch.contiguous_format)
+                if buf.data_ptr() != t.data_ptr():
+                    buf.copy_(t)
+                out[k] = buf
+        return out
 
     def _grads_ready(self, module) -> None:
         """Record that the gradient slice of ``module`` is final (handed to ``grad_hook`` after the segment)."""
@@ -463,11 +489,13 @@ class MAEEngine(EngineBase):
         ev = torch.cuda.Event()
         ev.record()
         self._h2d_done[slot] = ev
-        batch = dict(batch)
         for s in self.mods.values():
             img = batch[s.name]
             if img.dtype != F32 or not img.is_contiguous() or not img.is_cuda:
                 raise ValueError(f"batch[{s.name!r}] must be a contiguous float32 GPU tensor")
+        batch = self._stable_inputs(batch)
+        for s in self.mods.values():
+            img = batch[s.name]
             if tuple(img.shape[-2:]) != (s.S, s.S) or self.model.interpolate != "nearest":
                 # input staging (mim.py:427-432): resize to image_size on the GPU into an engine-owned buffer
                 mode = {"nearest": 0, "bilinear": 1, "bicubic": 2}.get(self.model.interpolate)

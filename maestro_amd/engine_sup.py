@@ -139,6 +139,17 @@ class SupervisedEngine(EngineBase):
             img = batch[s.name]
             if img.dtype != F32 or not img.is_contiguous() or not img.is_cuda:
                 raise ValueError(f"batch[{s.name!r}] must be a contiguous float32 GPU tensor")
+        for t, c in self.model.dataset.targets.items():
+            y = batch[t]
+            if not y.is_cuda or not y.is_contiguous():
+                raise ValueError(f"batch[{t!r}] must be a contiguous GPU tensor")
+            if c.type_target == "multilabel_classif" and y.dtype != F32:
+                batch[t] = y.float()
+            elif c.type_target != "multilabel_classif" and y.dtype.is_floating_point:
+                batch[t] = y.long()
+        batch = self._stable_inputs(batch)
+        for s in self.mods.values():
+            img = batch[s.name]
             if tuple(img.shape[-2:]) != (s.S, s.S) or self.model.interpolate != "nearest":
                 mode = {"nearest": 0, "bilinear": 1, "bicubic": 2}.get(self.model.interpolate)
                 if mode is None:
@@ -148,14 +159,6 @@ class SupervisedEngine(EngineBase):
                     buf = self.mb[s.name]["resized"] = torch.empty(self.B, s.Dates, s.C, s.S, s.S, dtype=F32, device=self.device)
                 hip.resize(img, buf, self.B * s.Dates * s.C, img.shape[-2], img.shape[-1], s.S, s.S, mode)
                 batch[s.name] = buf
-        for t, c in self.model.dataset.targets.items():
-            y = batch[t]
-            if not y.is_cuda or not y.is_contiguous():
-                raise ValueError(f"batch[{t!r}] must be a contiguous GPU tensor")
-            if c.type_target == "multilabel_classif" and y.dtype != F32:
-                batch[t] = y.float()
-            elif c.type_target != "multilabel_classif" and y.dtype.is_floating_point:
-                batch[t] = y.long()
         self._staged = batch
         key = self._cur_key = tuple(batch[k].data_ptr() for k in sorted(batch) if isinstance(batch[k], torch.Tensor))
         with self._tuning_pass("forward"):
