@@ -230,6 +230,9 @@ int mh_bce_loss(const float* logits, const float* target, float missing_val, flo
 /* ---------------------------------------------------------------------------------------------- misc
  * column sums: out[n] += sum_m x[m, n]  (bias gradients); x bf16 or f32; atomically accumulated. */
 int mh_colsum(const void* x, int x_is_f32, float* out, int M, int N, int ld, void* stream);
+/* Zero n_spans (offset, length) float ranges of one buffer (spans: device array of 2*n_spans longs; max_len = longest span).
+ * Used to clear only the atomically accumulated gradient slots when the weight gradients are stored by the grouped GEMM. */
+int mh_zero_spans(float* base, const long* spans_device, int n_spans, long max_len, void* stream);
 /* f32 -> bf16 cast of a flat buffer (weight shadow copies). */
 int mh_cast_bf16(const float* src, void* dst, long n, void* stream);
 /* f32 [E, K] -> bf16 [E, Kpad] (zero padded rows: patch-embed conv weight [E, C*P*P]) and the transpose for grads:

@@ -78,6 +78,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
     }
 }
 
+// zero a list of (offset, length) float spans of one buffer: blockIdx.y = span, blockIdx.x walks it in 1024-float pieces
+__global__ __launch_bounds__(256) void zero_spans_kernel(float* __restrict__ base, const long* __restrict__ spans) {
+    const long off = spans[2 * blockIdx.y], len = spans[2 * blockIdx.y + 1];
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < len; i += (long)gridDim.x * 1024) {
+        float* p = base + off + i;
+        if (i + 3 < len && (reinterpret_cast<uintptr_t>(p) & 15) == 0) *reinterpret_cast<f32x4*>(p) = (f32x4){0, 0, 0, 0};
+        else for (long e = i; e < min(len, i + 4); ++e) base[off + e] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
@@ -151,6 +161,14 @@ extern "C" int mh_colsum(const void* x, int x_is_f32, float* out, int M, int N, 
     while (rows_per_block > 32 && (long)col_blocks * ceil_div(M, rows_per_block) < 1024) rows_per_block >>= 1;
     hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 256), ceil_div(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream, x,
                        x_is_f32, out, M, N, ld, rows_per_block);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_zero_spans(float* base, const long* spans_device, int n_spans, long max_len, void* stream) {
+    MH_CHECK_ARG(base && spans_device && n_spans > 0 && max_len > 0, "mh_zero_spans: bad arguments");
+    dim3 grid((unsigned)min(64L, (max_len + 1023) / 1024), n_spans);
+    hipLaunchKernelGGL(zero_spans_kernel, grid, dim3(256), 0, (hipStream_t)stream, base, spans_device);
     MH_LAUNCH_CHECK();
     return 0;
 }

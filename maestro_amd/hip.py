@@ -318,6 +318,10 @@ def bce_loss(logits, target, missing_val, acc, dlogits, B, C):  # noqa: N803
     call("mh_bce_loss", logits, target, _F(float(missing_val)), acc, dlogits, _I(B), _I(C))
 
 
+def zero_spans(base, spans, n_spans, max_len):
+    call("mh_zero_spans", base, spans, _I(n_spans), _L(max_len))
+
+
 def colsum(x, out, M, N, ld):
     call("mh_colsum", x, _I(1 if x.dtype == torch.float32 else 0), out, _I(M), _I(N), _I(ld))
 
