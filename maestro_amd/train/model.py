@@ -29,6 +29,9 @@ except Exception:  # noqa: BLE001
         def log(self, *a, **k):
             return None
 
+        def setup(self, stage=None):   # LightningModule hook the reference's tests call (tests/test_model.py)
+            return None
+
 
 class MeanMetric(nn.Module):
     """Minimal stand-in for ``torchmetrics.MeanMetric`` (running mean of a scalar; ``base.py:52-56``)."""

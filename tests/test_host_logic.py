@@ -30,6 +30,16 @@ def test_mae_constructs(fusion_mode):
     assert "mask_token.s1_asc" in m.state_dict() and "enc_pos_encoding" not in m.state_dict()
 
 
+# tests/test_mae.py:42-74 of the reference: test_mae_architecture
+@pytest.mark.parametrize("interpolate,type_head,fac_abs_enc,fac_date_enc", itertools.product(
+    ["nearest", "bilinear"], ["attentive", "linear"], [1.0, 0.0], [1.0, 0.0]))
+def test_mae_architecture_like_reference(interpolate, type_head, fac_abs_enc, fac_date_enc):
+    m = mae_tiny(datasets=treesat(), mask=conf.MaskConfig(), interpolate=interpolate, fusion_mode="group", model="mae",
+                 inter_depth=0, num_levels=1, type_head=type_head, fac_abs_enc=fac_abs_enc, fac_date_enc=fac_date_enc)
+    assert m.interpolate == interpolate and m.fac_date_enc == fac_date_enc
+    assert float(m.enc_pos_encoding.abs().max()) == (0.0 if fac_abs_enc == 0.0 else 1.0)
+
+
 @pytest.mark.parametrize("factory,params_m", [(mae_medium, 176.2), (mae_large, None), (mae_small, None)])
 def test_sizes_and_state_dict_keys_match_oracle(factory, params_m):
     ds = conf.DatasetsConfig(name_dataset="flair", flair=conf.FLAIRConfig(filter_inputs=["aerial", "s2"], filter_targets=[]))
@@ -52,6 +62,24 @@ def test_ssl_module_constructs(fusion_mode, inter_depth, loss):
     assert any(k.startswith("model.encoder.") for k in mod.state_dict())
 
 
+# tests/test_model.py:66-100 of the reference: test_ssl_architecture (interpolate x head type x loss, then .setup(stage))
+@pytest.mark.parametrize("interpolate,type_head,loss,stage", itertools.product(
+    ["nearest", "bilinear"], ["attentive", "linear"], ["l1_norm", "l1"], ["train", "val", "test"]))
+def test_ssl_architecture_like_reference(interpolate, type_head, loss, stage):
+    mod = SSLModule(datasets=treesat(), mask=conf.MaskConfig(), interpolate=interpolate, fusion_mode="group", inter_depth=0,
+                    model="mae", model_size="tiny", type_head=type_head, loss=loss)
+    mod.setup(stage=stage)
+    head = mod.model.heads["treesat_mlc_thresh"]
+    assert hasattr(head, "reduce") == (type_head == "attentive") and head.linear.out_features == 15
+
+
+@pytest.mark.parametrize("fusion_mode,stage", itertools.product(["shared", "monotemp", "mod", "group"], ["train", "val", "test"]))
+def test_ssl_mae_like_reference(fusion_mode, stage):        # tests/test_model.py:8-34
+    mod = SSLModule(datasets=treesat(), mask=conf.MaskConfig(), interpolate="nearest", fusion_mode=fusion_mode, inter_depth=0,
+                    model="mae", model_size="tiny")
+    mod.setup(stage=stage)
+
+
 def test_ssl_module_errors():
     with pytest.raises(NotImplementedError):
         SSLModule(datasets=treesat(), mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="shared", inter_depth=3,
@@ -62,6 +90,11 @@ def test_ssl_module_errors():
     with pytest.raises(ValueError):
         SSLModule(datasets=treesat(), mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=0,
                   model="mae", model_size="tiny", loss="l3")
+    with pytest.raises(ValueError):      # tests/test_model.py:135-145 (xfail in the reference): unknown model name
+        SSLModule(datasets=treesat(), mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=0,
+                  model="MAE", model_size="tiny")
+    with pytest.raises(TypeError):       # tests/test_model.py:147-149: missing constructor arguments
+        SSLModule(model="mae", model_size="tiny")
 
 
 def test_positional_tables_match_oracle():
