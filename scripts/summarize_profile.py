@@ -16,7 +16,8 @@ dst.mkdir(exist_ok=True)
 shutil.copy(src / f"{tag}_kernel_stats.csv", dst / f"{tag}_kernel_stats.csv")
 
 _LAYOUT = {("false", "false"): "NT", ("false", "true"): "NN", ("true", "true"): "TN"}
-_TILE = {"2, 4, 4": "256x256", "2, 2, 3": "256x128", "1, 4, 3": "128x256", "1, 2, 4": "128x128"}
+_TILE = {"2, 4, 4, 8": "256x256", "2, 2, 3, 8": "256x128", "1, 4, 3, 8": "128x256", "1, 2, 4, 8": "128x128",
+         "2, 2, 4, 4": "128x128q"}
 
 
 def short(name):
