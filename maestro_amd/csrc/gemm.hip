@@ -165,11 +165,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmParams p) {
         for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_KMAJOR>(ta, wm + 16 * i, s);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR>(tb, wn + 16 * j, s);
+        __builtin_amdgcn_s_setprio(1);   // favour the wave that has its fragments: +0.5-1.5 % (it issues its MFMAs back to back)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
     };
     if (p.fast) {
         const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)p.a_bytes, 0x00020000);
