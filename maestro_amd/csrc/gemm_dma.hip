@@ -135,7 +135,6 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
         else if (younger == 1) wait_vmcnt<PA + PB>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();   // everybody's pieces of step t are in LDS; step t-1 has been read by everybody
-        if (t + S - 1 < nk) issue(t + S - 1);   // refill the slot step t-1 just vacated
         const unsigned char* ta = smem + (t % S) * T::STAGE_BYTES;
         const unsigned char* tb = ta + T::A_BYTES;
         bf16x8 fa[MT], fb[4];
@@ -147,7 +146,15 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
         // interleaves them two fragments at a time to save registers and every group of 4 MFMAs then waits on LDS: +2 %)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT / 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + S - 1 < nk) issue(t + S - 1);   // refill the slot step t-1 just vacated, behind the first half's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = MT / 2; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
