@@ -142,19 +142,16 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
         for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR, T::BN>(tb, wn + 16 * j);
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[i] = read_frag<A_KMAJOR, T::BM>(ta, wm + 16 * i);
-        // keep all 24 fragment reads of the K step in flight before the first MFMA issues (left alone, the scheduler
-        // interleaves them two fragments at a time to save registers and every group of 4 MFMAs then waits on LDS: +2 %)
+        // Order matters: (1) all 24 fragment reads of the K step go out first (left alone, the scheduler interleaves them two
+        // fragments at a time to save registers and every group of 4 MFMAs then waits on LDS: +2 %); (2) only then the DMA
+        // pieces that refill the slot step t-1 vacated -- an LDS-DMA instruction costs the wave ~100 issue cycles, and issued
+        // in front of the reads (as this kernel first did) it held the whole step back: grouped wgrad 754 -> 1050 TFLOP/s;
+        // (3) the MFMAs, whose operands arrive while the DMA instructions issue.
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + S - 1 < nk) issue(t + S - 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < MT / 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + S - 1 < nk) issue(t + S - 1);   // refill the slot step t-1 just vacated, behind the first half's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = MT / 2; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
