@@ -292,15 +292,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmParams p) {
 
 }  // namespace
 
-// Dispatch rule for the large-tile LDS-DMA kernel (gemm_dma.hip), from scripts/bench_gemm3.py on MI355X: it wins (x1.10 to
-// x1.35) for NT problems whose 256x256 tiles fill the 256 CUs in whole waves (>= 90 % wave efficiency); it loses when the
-// tile count quantises badly (M = 8192 encoder shapes), for K-major operands and for split-K wgrads (more splits -> more
-// fp32 atomic passes).  MH_GEMM_DMA=0 disables it, MH_GEMM_DMA=1 forces it wherever it is eligible (experiments).
+// Dispatch rule for the large-tile LDS-DMA kernel (gemm_dma.hip), from scripts/bench_tiles.py on MI355X: it wins (x1.05 to
+// x1.2, x1.8 on the K = 512 dgrad) for NT and NN problems whose 256x256 tiles fill the 256 CUs in whole waves (>= 90 % wave
+// efficiency: the M = 32768 decoder shapes); it loses when the tile count quantises badly (M = 8192 encoder shapes) and for
+// split-K wgrads (more splits -> more fp32 atomic passes).  MH_GEMM_DMA=0 disables it, MH_GEMM_DMA=1 forces it wherever it
+// is eligible (experiments).
 static bool prefer_dma(int layout, int M, int N, int K, int flags) {
     const char* e = getenv("MH_GEMM_DMA");
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return true;
-    if (layout != 0 || (flags & MH_GEMM_ATOMIC) || K % 32 != 0 || K < 256) return false;
+    if (layout == 2 || (flags & MH_GEMM_ATOMIC) || K % 32 != 0 || K < 256) return false;
     const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256);
     if (tiles < 256) return false;
     const long waves = (tiles + 255) / 256;

@@ -396,7 +396,7 @@ def _uses_dma(layout, M, N, K, flags) -> bool:
     e = os.environ.get("MH_GEMM_DMA", "")
     if e[:1] == "0":
         return False
-    if layout != GEMM_NT or (flags & ATOMIC) or K % 32 or K < 256:
+    if layout == GEMM_TN or (flags & ATOMIC) or K % 32 or K < 256:
         return False
     tiles = -(-M // 256) * -(-N // 256)
     waves = -(-tiles // 256)
