@@ -623,23 +623,23 @@ class MAEEngine(EngineBase):
         hip.zero_spans(self.store.grad, z[0], z[1], z[2])
 
     # Minimum number of 256x256 output tiles for which one grouped wgrad launch beats the per-GEMM split-K launches
-    # (measured on C3: 1944 tiles 3.25 -> 2.01 ms, 384 tiles 1.92 -> 1.86 ms, 324 tiles 0.81 -> 0.91 ms; 256 CUs).
-    WGRAD_MIN_TILES = 512
+    # (measured on C3: 1944 tiles 3.10 -> 1.47 ms, 384 tiles 1.83 -> 1.17 ms, 324 tiles 0.79 -> 0.57 ms; 256 CUs).
+    WGRAD_MIN_TILES = 256
 
     def _wgrad_plan(self) -> str:
         """"fused" | "all" (every stack deferred into ONE launch at the end of the backward; only without a gradient hook,
-        because every weight gradient then completes last) | "enc" (data parallel: one grouped launch per encoder
-        segment, so finished slices still overlap the all-reduce; the decoder / joint weight gradients -- 324-384 tiles, too
-        few for a launch of their own -- ride along with the first encoder segment's launch and are reported ready there)."""
+        because every weight gradient then completes last) | "enc" (data parallel: one grouped launch at the end of EVERY
+        backward segment -- decoder side, joint encoder, each encoder chunk -- so that finished slices are handed to the
+        all-reduce as early as with in-line weight gradients)."""
         if self.wgrad_mode == "fused":
             return "fused"
         hooked = self.grad_hook is not None
         plan = self._wgrad_plans.get((self.wgrad_mode, hooked))
         if plan is not None:
             return plan
-        stacks = list(self.enc.values()) if hooked else self._all_stacks()
         try:
-            tiles = [hip.GroupedTN.count_tiles(st.wgrad_problems()) for st in stacks]
+            every = {st.tag: hip.GroupedTN.count_tiles(st.wgrad_problems()) for st in self._all_stacks()}
+            tiles = [every[st.tag] for st in self.enc.values()] if hooked else list(every.values())
             ok = True
         except hip.HipExtensionError:
             tiles, ok = [], False
@@ -720,7 +720,7 @@ class MAEEngine(EngineBase):
                                       None, dx, dx16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(), gbuf["ln_ws"],
                                       s.Beff, s.n_tok, Dd)
                     self._grads_ready(m.embed_to_rec[s.embed])
-                dx0, _ = st.backward(dx, defer=self._plan in ("all", "enc"), ready=self._plan != "enc")
+                dx0, _ = st.backward(dx, defer=self._plan in ("all", "enc"))
                 self._grads_ready(nrm)
                 # unmask backward: visible rows -> enc_to_dec output grad; masked rows -> mask-token grads
                 hip.gather_rows(dx0, gbuf["vis"], gbuf["dy_e2d"], g.Beff, g.L, g.N, Dd, g.N, 0)
@@ -744,11 +744,15 @@ class MAEEngine(EngineBase):
             return run
 
         self._run_parallel([side(g) for g in self.groups])
+        if self._plan == "enc":
+            self._launch_wgrads([(st, 0, st.depth) for st in self.dec.values()])
 
     def _bwd_joint(self) -> None:
         jt = self.joint
-        self._djoint, _ = jt.backward(jt.dxa, defer=self._plan in ("all", "enc"), ready=self._plan != "enc")
+        self._djoint, _ = jt.backward(jt.dxa, defer=self._plan in ("all", "enc"))
         self._grads_ready(jt.t.norm)
+        if self._plan == "enc":
+            self._launch_wgrads([(jt, 0, jt.depth)])
 
     def _bwd_encoder_side(self, hi: int, lo: int, first: bool, last: bool) -> None:
         """Layers ``hi-1 .. lo`` of every group encoder (groups on parallel streams); ``first`` also runs the final-LN
@@ -794,13 +798,8 @@ class MAEEngine(EngineBase):
             return run
 
         self._run_parallel([side(g) for g in self.groups])
-        if self._plan == "enc":      # this segment's layers of every group encoder (+ decoder / joint with the first one)
-            items = [(st, min(lo, st.depth), min(hi, st.depth)) for st in self.enc.values()]
-            late = (list(self.dec.values()) + ([self.joint] if self.joint is not None else [])) if first else []
-            self._launch_wgrads(items + [(st, 0, st.depth) for st in late])
-            for st in late:
-                for layer in st.t.layers:
-                    self._grads_ready(layer)
+        if self._plan == "enc":      # this segment's layers of every group encoder
+            self._launch_wgrads([(st, min(lo, st.depth), min(hi, st.depth)) for st in self.enc.values()])
         elif self._plan == "all" and last:
             self._launch_wgrads([(st, 0, st.depth) for st in self._all_stacks()])
         if last:
