@@ -263,6 +263,7 @@ class SupervisedEngine(EngineBase):
         if fine:
             self.dxenc.zero_()
         first_ref = True
+        head_wgrads = []     # (A = dY, B = X, dW, M, N, K = token rows, lda, ldb, ldc): issued as one grouped launch below
         for t, hb in self.hb.items():
             head = m.heads[t]
             seg = hb["kind"] == "segment"
@@ -287,7 +288,7 @@ class SupervisedEngine(EngineBase):
                     hip.colsum(hb["dlogits"], hb["dbp"], n, W, W)
                     hip.unpack_rows_add(hb["dbp"], ps.g(head.conv.bias), 1, hb["PPC"], W)
                 else:
-                    hip.gemm(hip.GEMM_TN, W, E, n, hb["dlogits"], W, hb["hfc"], E, ps.g(head.conv.weight).view(W, E), E, AT)
+                    head_wgrads.append((hb["dlogits"], hb["hfc"], ps.g(head.conv.weight).view(W, E), W, E, n, W, E, E))
                     hip.colsum(hb["dlogits"], ps.g(head.conv.bias), n, W, W)
             else:
                 feat = hb["h"] if hb["attentive"] else hb["red"]
@@ -306,7 +307,7 @@ class SupervisedEngine(EngineBase):
                 hip.attn_reduce_bwd(hb["kv"], red.query, hb["red"], hb["lse"], hb["dred"], hb["dkv"], hb["dq_part"], B, hb["T"],
                                     hb["Lr"], E, red.heads)
                 hip.colsum(hb["dq_part"], ps.g(red.query), hb["dq_part"].shape[0], E, E)
-                hip.gemm(hip.GEMM_TN, 2 * E, E, R, hb["dkv"], 2 * E, hb["xn"], E, ps.g(red.to_kv.weight), E, AT)
+                head_wgrads.append((hb["dkv"], hb["xn"], ps.g(red.to_kv.weight), 2 * E, E, R, 2 * E, E, E))
                 hip.gemm(hip.GEMM_NN, R, E, 2 * E, hb["dkv"], 2 * E, ps.h(red.to_kv.weight), E, hb["dxn"], E)
                 hip.layernorm_bwd(hb["dxn"], R, 0, x, R, 0, red.norm.weight, hb["mean_n"], hb["rstd_n"], dres, dx, None,
                                   ps.g(red.norm.weight), ps.g(red.norm.bias), None, self.ln_ws, 1, R, E)
@@ -319,12 +320,40 @@ class SupervisedEngine(EngineBase):
             if seg:
                 first_ref = False
             self._grads_ready(head)
+        self._launch_head_wgrads(head_wgrads)
         if fine and self.ref is not None and not first_ref:      # transposed resize: reference grid -> each modality's tokens
             r, d0 = self.ref, 0
             for s in self.mods.values():
                 hip.token_resize_bwd(r["dx"], r["TD"] * r["Lr"], d0 * r["Lr"], self.dxenc, self.JL, self.goff[s.group] + s.tok_off, B,
                                      s.D, s.g, r["G"], E, accumulate=True)
                 d0 += s.D
+
+    HEAD_K_CHUNK = 32768   # token rows per grouped-GEMM problem: a head sees up to B * dates * L_ref = 557 k rows
+
+    def _launch_head_wgrads(self, probs) -> None:
+        """The heads' weight gradients (few output tiles, very long K = token rows) as ONE grouped launch: every problem is
+        cut along K into chunks that accumulate atomically into the zeroed gradient slot -- the grouped kernel's own form of
+        split-K, at its ~1 PFLOP/s instead of the per-GEMM split-K launches."""
+        if not probs:
+            return
+        if not hasattr(self, "_head_table"):
+            chunks = []
+            for (A, B, C, M, N, K, lda, ldb, ldc) in probs:  # noqa: N806
+                nchunk = max(2, -(-K // self.HEAD_K_CHUNK))  # >= 2 problems per dW -> atomic accumulation into the zeroed slot
+                step = -(-K // nchunk)
+                for k0 in range(0, K, step):
+                    k1 = min(K, k0 + step)
+                    chunks.append((A[k0:k1], B[k0:k1], C, M, N, k1 - k0, lda, ldb, ldc))
+            try:
+                self._head_table = hip.GroupedTN(chunks, self.device)
+            except hip.HipExtensionError:
+                self._head_table = None
+        if self._head_table is not None:
+            self._head_table.launch()
+            return
+        AT = hip.OUT_F32 | hip.ATOMIC  # noqa: N806
+        for (A, B, C, M, N, K, lda, ldb, ldc) in probs:  # noqa: N806
+            hip.gemm(hip.GEMM_TN, M, N, K, A, lda, B, ldb, C, ldc, AT)
 
     def _wgrad_deferred(self) -> bool:
         if os.environ.get("MAESTRO_WGRAD") == "fused":
