@@ -190,6 +190,8 @@ def main() -> None:
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: no group-parallel streams (clean per-kernel times)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--rehearse-exchange", action="store_true",
+                    help="N=1 under torch.distributed.run: create the one-rank RCCL group and run the bucketed exchange plan")
     ap.add_argument("--shapes", action="store_true", help="print per-shape kernel times to stderr (diagnostic)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -214,7 +216,7 @@ def main() -> None:
     local = local % max(ndev, 1)   # only differs from LOCAL_RANK in single-GPU gloo rehearsals
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.rehearse_exchange:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -225,7 +227,8 @@ def main() -> None:
     torch.manual_seed(42 + rank)
     ds, model = build_model(args.config, args.phase)
     if args.phase == "pretrain":
-        loop = PretrainLoop(model, args.batch, dev, loss=args.loss, total_steps=args.steps + args.warmup, world_size=world)
+        loop = PretrainLoop(model, args.batch, dev, loss=args.loss, total_steps=args.steps + args.warmup, world_size=world,
+                            exchange=True if args.rehearse_exchange else None)
     else:
         loop = SupervisedLoop(model, args.batch, dev, phase=args.phase, total_steps=args.steps + args.warmup, world_size=world)
     batch = synthetic_batch(ds.dataset, args.batch, dev, seed=rank)
@@ -247,6 +250,7 @@ def main() -> None:
     t_issue = time.perf_counter() - t0   # host time to issue the steps (diagnostic: host-bound if ~= elapsed)
     sync()
     elapsed = time.perf_counter() - t0
+    loss_val = float(loss.item())   # the engine's loss buffer is static: read it before the roofline leg runs more steps
     # Roofline leg: the same steps once more with HIP events around every MFMA-kernel launch on its stream (event
     # pairs cannot be recorded inside a captured graph, so these steps are launched eagerly; kernels are identical).
     timer = None if args.no_kernel_timing else hip.KernelTimer()
@@ -262,7 +266,6 @@ def main() -> None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_val = float(loss.item())
 
     if rank == 0:
         tiles = args.batch * world * args.steps
@@ -298,7 +301,7 @@ def main() -> None:
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds, args.phase)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

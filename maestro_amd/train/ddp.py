@@ -18,6 +18,8 @@ class GradSync:
     def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 64 << 20, group=None) -> None:
         self.grad, self.group = flat_grad, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # a one-rank group still exchanges when it exists: `bench.py --rehearse-exchange` drives the RCCL launch plan on one GPU
+        self.exchange = dist.is_available() and dist.is_initialized()
         self.bucket = max(1, bucket_bytes // flat_grad.element_size())
         self.launched: list[tuple[int, int]] = []
         self.begin()
@@ -32,7 +34,7 @@ class GradSync:
         if hi <= lo:
             return
         self.launched.append((lo, hi))
-        if self.world > 1:
+        if self.exchange:
             self.works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def ready(self, lo: int, hi: int) -> None:

@@ -31,13 +31,14 @@ def synthetic_batch(dataset, B: int, device, seed: int = 0) -> dict:  # noqa: N8
 class PretrainLoop:
     def __init__(self, model, batch_size: int, device, loss: str = "l2_norm", base_lr: float = 3e-5,
                  betas=(0.9, 0.99), weight_decay: float = 0.01, total_steps: int = 1000, world_size: int = 1,
-                 final_factor: float = 1e7, bucket_mb: int = 64) -> None:
+                 final_factor: float = 1e7, bucket_mb: int = 64, exchange: bool | None = None) -> None:
         self.engine = model.engine(batch_size, device, loss=loss)
         lr = scaled_lr(base_lr, batch_size, 1, 1, world_size)
         self.sched = OneCycle(lr, max(total_steps, 2), pct_start=0.2, div_factor=1000.0,
                               final_div_factor=final_factor / 1000.0)
         self.opt = FusedAdamW(self.engine, lr, betas=betas, weight_decay=weight_decay)
-        self.sync = GradSync(self.engine.store.grad, bucket_bytes=bucket_mb << 20) if world_size > 1 else None
+        exchange = world_size > 1 if exchange is None else exchange   # True at world_size 1: one-rank rehearsal of the launch plan
+        self.sync = GradSync(self.engine.store.grad, bucket_bytes=bucket_mb << 20) if exchange else None
         if self.sync is not None:
             self.engine.grad_hook = self.sync.ready
         self.it = 0
