@@ -62,12 +62,23 @@ class _EngineLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         eng = ctx.engine
+        st = eng.store
+        lo, hi = getattr(eng, "trainable_span", (0, st.total))
+        # Gradient accumulation (Lightning's accumulate_grad_batches, ``conf/trainer.py``): the engine STORES its gradients,
+        # so when the previous micro-batch's gradients are still attached (no zero_grad in between) they are set aside
+        # and added back after this backward -- autograd's "+=" semantics at the cost of one pass over the flat buffer.
+        live = any(p.grad is not None and p.grad.data_ptr() == st.g(p).data_ptr() for p in st.params
+                   if lo <= st.offset[id(p)] < hi)
+        if live:
+            if getattr(st, "grad_acc", None) is None:
+                st.grad_acc = torch.empty_like(st.grad)
+            st.grad_acc.copy_(st.grad)
         eng.zero_grad()
         eng.backward()
-        st = eng.store
         if not (isinstance(grad_out, torch.Tensor) and grad_out.numel() == 1 and float(grad_out) == 1.0):
-            st.grad.mul_(grad_out.reshape(()))  # e.g. gradient accumulation / loss scaling by the trainer
-        lo, hi = getattr(eng, "trainable_span", (0, st.total))
+            st.grad.mul_(grad_out.reshape(()))  # loss / accumulate_grad_batches, or a trainer's loss scaling
+        if live:
+            st.grad.add_(st.grad_acc)
         for p in st.params:  # re-attach views if the trainer cleared them (zero_grad(set_to_none=True))
             if not lo <= st.offset[id(p)] < hi:
                 p.grad = None   # probe: detached encoder features -> no gradient (the optimizer then skips the parameter)

@@ -31,9 +31,10 @@ def synthetic_batch(dataset, B: int, device, seed: int = 0) -> dict:  # noqa: N8
 class PretrainLoop:
     def __init__(self, model, batch_size: int, device, loss: str = "l2_norm", base_lr: float = 3e-5,
                  betas=(0.9, 0.99), weight_decay: float = 0.01, total_steps: int = 1000, world_size: int = 1,
-                 final_factor: float = 1e7, bucket_mb: int = 64, exchange: bool | None = None) -> None:
+                 final_factor: float = 1e7, bucket_mb: int = 64, exchange: bool | None = None,
+                 accumulate: int = 1) -> None:
         self.engine = model.engine(batch_size, device, loss=loss)
-        lr = scaled_lr(base_lr, batch_size, 1, 1, world_size)
+        lr = scaled_lr(base_lr, batch_size, accumulate, 1, world_size)   # model.py:120-128: micro-batches count towards the batch
         self.sched = OneCycle(lr, max(total_steps, 2), pct_start=0.2, div_factor=1000.0,
                               final_div_factor=final_factor / 1000.0)
         self.opt = FusedAdamW(self.engine, lr, betas=betas, weight_decay=weight_decay)
@@ -43,7 +44,13 @@ class PretrainLoop:
             self.engine.grad_hook = self.sync.ready
         self.it = 0
 
-    def step(self, batch: dict) -> torch.Tensor:
+    def step(self, batch) -> torch.Tensor:
+        """One optimizer step.  ``batch``: a batch dict, or a list of micro-batch dicts (gradient accumulation, the
+        reference trainer's ``accumulate_grad_batches``): their gradients are averaged; returns the last loss."""
+        if isinstance(batch, (list, tuple)) and len(batch) > 1:
+            return self._step_accumulated(list(batch))
+        if isinstance(batch, (list, tuple)):
+            batch = batch[0]
         eng = self.engine
         loss = eng.forward(batch)
         eng.zero_grad()
@@ -56,6 +63,34 @@ class PretrainLoop:
             self.opt.step(lr=self.sched.lr(self.it), grad_scale=scale, split=split, between=wait_tail)
         else:
             self.opt.step(lr=self.sched.lr(self.it), grad_scale=scale)
+        self.it += 1
+        return loss
+
+    def _step_accumulated(self, micro: list) -> torch.Tensor:
+        """The engine stores (does not add) its gradients, so micro-batches are summed in a second flat buffer (one
+        read-modify-write pass per micro-batch) and exchanged once, after the last one -- no overlap with backward here."""
+        eng, st = self.engine, self.engine.store
+        if getattr(st, "grad_acc", None) is None:
+            st.grad_acc = torch.empty_like(st.grad)
+        hook, eng.grad_hook = eng.grad_hook, None
+        try:
+            for i, mb in enumerate(micro):
+                loss = eng.forward(mb)
+                eng.zero_grad()
+                eng.backward()
+                if i == 0:
+                    st.grad_acc.copy_(st.grad)
+                elif i < len(micro) - 1:
+                    st.grad_acc.add_(st.grad)
+                else:
+                    st.grad.add_(st.grad_acc)
+        finally:
+            eng.grad_hook = hook
+        scale = 1.0 / len(micro)
+        if self.sync is not None:
+            self.sync.begin()
+            scale *= self.sync.finish()
+        self.opt.step(lr=self.sched.lr(self.it), grad_scale=scale)
         self.it += 1
         return loss
 

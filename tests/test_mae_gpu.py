@@ -287,3 +287,58 @@ def test_loader_fed_batches_keep_graph_replay(golden_dir):
         assert abs(loss - ref[0]) <= 1e-5 * abs(ref[0]), (it, loss, ref[0])
     assert all(eng2._inputs[k]["buf"] is not None for k in ("aerial", "s2"))
     assert "forward" in eng2._graphs and any(k.startswith("bwd_dec") for k in eng2._graphs)
+
+
+def test_gradient_accumulation_sums_micro_batches():
+    """accumulate_grad_batches (reference ``conf/trainer.py``, lr rule ``model.py:120-128``): the engine stores its gradients,
+    so both surfaces add micro-batches explicitly -- Lightning style (two backward() calls without zero_grad in between,
+    loss divided by 2) and ``PretrainLoop.step([mb1, mb2])``.  Both must equal the hand-made mean of the two gradients."""
+    from types import SimpleNamespace
+
+    from maestro_amd.train.model import SSLModule
+    from maestro_amd.train.trainer import PretrainLoop, synthetic_batch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    ds = conf.DatasetsConfig(name_dataset="treesatai_ts", treesatai_ts=conf.TreeSatAITSConfig(
+        filter_targets=[], aerial=conf.InputRasterConfig(image_size=60, patch_size=conf.PatchSizeConfig(mae=20), bands=4,
+                                                         norm_bands=[1, 3], norm_fac=255.0)))
+    torch.manual_seed(0)
+    mod = SSLModule(datasets=ds, mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=3,
+                    model="mae", model_size="tiny", loss="l2_norm", use_ema=False)
+    mod.trainer = SimpleNamespace(ssl_phase="pretrain")
+    mbs = [synthetic_batch(ds.dataset, 2, dev, seed=s) for s in (1, 2)]
+    eng = mod.model.engine(2, dev, loss="l2_norm")
+    st = eng.store
+    single = []
+    for i, mb in enumerate(mbs):                  # reference: each micro-batch on its own, fixed mask seeds
+        torch.manual_seed(20 + i)
+        eng.forward(mb)
+        eng.zero_grad()
+        eng.backward()
+        single.append(st.grad.clone())
+    want = 0.5 * (single[0] + single[1])
+    assert (single[0] - single[1]).norm() > 1e-3 * want.norm()
+    # Lightning style
+    for p in st.params:
+        p.grad = None
+    for i, mb in enumerate(mbs):
+        torch.manual_seed(20 + i)
+        (mod.training_step(mb, i)["loss"] / 2).backward()
+    torch.cuda.synchronize()
+    rel = ((st.grad - want).norm() / want.norm()).item()
+    assert rel < 1e-5, rel
+    assert all(p.grad.data_ptr() == st.g(p).data_ptr() for p in st.params)
+    # own loop: the optimizer sees the SUM with grad_scale 1/2
+    loop = PretrainLoop(mod.model, 2, dev, loss="l2_norm", accumulate=2)
+    assert loop.engine is eng
+    seen = {}
+    loop.opt.step = lambda lr=None, grad_scale=1.0, **kw: seen.update(g=st.grad.clone(), scale=grad_scale)
+    torch.manual_seed(20)                         # one seed for the pair: the manual replay below draws the same masks
+    loop.step(mbs)
+    assert seen["scale"] == 0.5
+    torch.manual_seed(20)
+    eng.forward(mbs[0]); eng.zero_grad(); eng.backward(); g0 = st.grad.clone()
+    eng.forward(mbs[1]); eng.zero_grad(); eng.backward(); g1 = st.grad.clone()
+    rel = ((seen["g"] - (g0 + g1)).norm() / (g0 + g1).norm()).item()
+    assert rel < 1e-5, rel
