@@ -30,22 +30,25 @@ class SupervisedEngine(EngineBase):
             raise hip.HipExtensionError("SupervisedEngine needs a GPU device; there is no CPU fallback")
         hip.lib()
         m = self.model = model
-        if m.fusion_mode not in ("group", "mod"):
-            raise NotImplementedError(f"probe / finetune with fusion_mode={m.fusion_mode!r} is not built (group, mod)")
+        fold = m.fusion_mode in ("shared", "monotemp")   # dates folded into the batch (utils.py:26-37): Beff = B * dates
+        if fold and m.encoder_inter is not None:
+            raise NotImplementedError(
+                f"Simultaneous encoding of all mods not yet compatible with fusion mode: {m.fusion_mode}.")  # model.py:65-67
         if not len(m.heads):
             raise ValueError("the dataset config selects no target (filter_targets): nothing to probe / finetune")
         self.B, self.phase, self.E = batch_size, phase, m.embed_dim
         self._init_runtime(device, len(m.group_specs) - 1)
         self.mods, self.groups = m.mod_specs, list(m.group_specs.values())
         for s in self.mods.values():
-            s.Beff = batch_size
+            s.Beff = batch_size * s.Dates if fold else batch_size
         for g in self.groups:
-            g.Beff = batch_size
-        # full-sequence geometry: group g occupies rows [goff, goff + L) of the joint sequence of JL tokens
-        self.goff, off = {}, 0
+            g.Beff = g.mods[0].Beff
+        # full-sequence geometry: group g occupies rows [goff, goff + Lb) of the JL tokens of one batch element, Lb = L
+        # (or dates * L when the dates are folded: the [B * dates, L, E] sequences ARE [B, dates * L, E] in memory)
+        self.goff, self.Lb, off = {}, {}, 0
         for g in self.groups:
-            self.goff[g.name] = off
-            off += g.L
+            self.goff[g.name], self.Lb[g.name] = off, g.L * (g.Beff // batch_size)
+            off += self.Lb[g.name]
         self.JL = off
         # ---- flat parameter store: encoder side first, heads last (probe trains the contiguous tail only)
         ordered = []
@@ -72,7 +75,7 @@ class SupervisedEngine(EngineBase):
         z = lambda *s, dt=F32: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
         self.mb, self.gb, self.enc = {}, {}, {}
         for name, s in self.mods.items():
-            T, BD = B * s.n_tok, B * s.D  # noqa: N806
+            T, BD = s.Beff * s.n_tok, s.Beff * s.D  # noqa: N806
             pe = m.patch_embed[s.embed].patchify_bands[0]
             self.mb[name] = dict(cols=e(T, s.Kpad, dt=BF16), yconv=e(T, E), gn_partial=e(hip.groupnorm_partial_size(BD, s.L, E)),
                                  gn_stats=e(BD, 2), gn_sums=e(BD, 2), pos_enc=m.pos_enc_rows[name].to(dev),
@@ -81,8 +84,8 @@ class SupervisedEngine(EngineBase):
         ws_rows = B * self.JL
         for g in self.groups:
             n_dates = sum(s.D for s in g.mods)
-            self.enc[g.name] = Stack(self, m.encoder[g.model], B, g.L, f"sup.enc.{g.name}")
-            self.gb[g.name] = dict(dates=z(B, n_dates, 8), n_dates=n_dates, mean_e=e(B * g.L), rstd_e=e(B * g.L))
+            self.enc[g.name] = Stack(self, m.encoder[g.model], g.Beff, g.L, f"sup.enc.{g.name}")
+            self.gb[g.name] = dict(dates=z(g.Beff, n_dates, 8), n_dates=n_dates, mean_e=e(g.Beff * g.L), rstd_e=e(g.Beff * g.L))
         self.joint = Stack(self, m.encoder_inter, B, self.JL, "sup.joint") if m.encoder_inter is not None else None
         self.xenc, self.dxenc = e(B, self.JL, E), e(B, self.JL, E)        # encoded tokens (after the last final LN) and their gradient
         self.mean_j, self.rstd_j = e(B * self.JL), e(B * self.JL)
@@ -94,7 +97,7 @@ class SupervisedEngine(EngineBase):
         seg = [t for t, c in ds.targets.items() if c.type_target == "segment"]
         if seg:
             G = m.out_grid_size[ds.ref_input]  # noqa: N806
-            TD = sum(s.D for s in self.mods.values())  # noqa: N806
+            TD = sum(s.Dates for s in self.mods.values())  # noqa: N806
             self.ref = dict(G=G, Lr=G * G, TD=TD, x=e(B, TD * G * G, E), dx=e(B, TD * G * G, E))
             ws_rows = max(ws_rows, B * TD * G * G)
         for t, c in ds.targets.items():
@@ -168,26 +171,31 @@ class SupervisedEngine(EngineBase):
     def _embed_encode(self, g, batch) -> None:
         m, E, B = self.model, self.E, self.B  # noqa: N806
         gbuf, st = self.gb[g.name], self.enc[g.name]
-        xg = st.x0.view(B, g.L, E)            # the embedding is written straight into the encoder's input (no masking)
+        xg = st.x0.view(g.Beff, g.L, E)       # the embedding is written straight into the encoder's input (no masking)
+        Lb = self.Lb[g.name]  # noqa: N806
         for s in g.mods:
             b = self.mb[s.name]
-            BD = B * s.D  # noqa: N806
+            BD = s.Beff * s.D  # noqa: N806
             hip.patchify(batch[s.name], b["cols"], None, BD, s.C, s.S, s.P, s.Kpad, b["norm_bands"], len(s.norm_bands), False,
                          s.rescale_elev)
-            hip.date_features(batch[f"{s.name}_dates"], batch["ref_date"], gbuf["dates"], B, s.D, gbuf["n_dates"], s.date_off,
-                              m.fac_date_enc)
+            if s.D != s.Dates:   # dates folded into the batch: one date row per sequence
+                hip.date_features(batch[f"{s.name}_dates"], batch["ref_date"], gbuf["dates"].view(B, s.Dates, 8), B, s.Dates,
+                                  s.Dates, 0, m.fac_date_enc)
+            else:
+                hip.date_features(batch[f"{s.name}_dates"], batch["ref_date"], gbuf["dates"], B, s.D, gbuf["n_dates"], s.date_off,
+                                  m.fac_date_enc)
             pe = b["pe"]
-            T = B * s.n_tok  # noqa: N806
+            T = s.Beff * s.n_tok  # noqa: N806
             hip.gemm(hip.GEMM_NT, T, E, s.Kpad, b["cols"], s.Kpad, b["w_conv16"], s.Kpad, b["yconv"], E, hip.OUT_F32 | hip.BIAS,
                      bias=pe.conv.bias)
             hip.groupnorm_stats(b["yconv"], b["gn_partial"], b["gn_stats"], BD, s.L, E)
             hip.embed_finish(b["yconv"], b["gn_stats"], pe.norm.weight, pe.norm.bias, b["pos_enc"], gbuf["dates"],
-                             gbuf["n_dates"], s.date_off, xg, B, s.D, s.L, E, s.tok_off, g.L)
+                             gbuf["n_dates"], s.date_off, xg, s.Beff, s.D, s.L, E, s.tok_off, g.L)
         st.forward()
         nrm = st.t.norm
         dst = self.joint.x0 if self.joint is not None else self.xenc
-        hip.layernorm_fwd(st.x_last, g.L, 0, nrm.weight, nrm.bias, dst, self.JL, self.goff[g.name], gbuf["mean_e"], gbuf["rstd_e"],
-                          B, g.L, E)
+        hip.layernorm_fwd(st.x_last, Lb, 0, nrm.weight, nrm.bias, dst, self.JL, self.goff[g.name], gbuf["mean_e"], gbuf["rstd_e"],
+                          B, Lb, E)
 
     def _forward_launches(self, batch: dict) -> None:
         m, E, B, ps = self.model, self.E, self.B, self.store  # noqa: N806
@@ -201,8 +209,8 @@ class SupervisedEngine(EngineBase):
             r, d0 = self.ref, 0
             for s in self.mods.values():
                 hip.token_resize(self.xenc, self.JL, self.goff[s.group] + s.tok_off, r["x"], r["TD"] * r["Lr"], d0 * r["Lr"], B,
-                                 s.D, s.g, r["G"], E)
-                d0 += s.D
+                                 s.Dates, s.g, r["G"], E)
+                d0 += s.Dates
         for t, hb in self.hb.items():
             head = m.heads[t]
             x = self.ref["x"] if hb["kind"] == "segment" else self.xenc
@@ -325,8 +333,8 @@ class SupervisedEngine(EngineBase):
             r, d0 = self.ref, 0
             for s in self.mods.values():
                 hip.token_resize_bwd(r["dx"], r["TD"] * r["Lr"], d0 * r["Lr"], self.dxenc, self.JL, self.goff[s.group] + s.tok_off, B,
-                                     s.D, s.g, r["G"], E, accumulate=True)
-                d0 += s.D
+                                     s.Dates, s.g, r["G"], E, accumulate=True)
+                d0 += s.Dates
 
     HEAD_K_CHUNK = 32768   # token rows per grouped-GEMM problem: a head sees up to B * dates * L_ref = 557 k rows
 
@@ -383,17 +391,17 @@ class SupervisedEngine(EngineBase):
         def side(g):
             def run():
                 gbuf, st = self.gb[g.name], self.enc[g.name]
-                nrm = st.t.norm
-                hip.layernorm_bwd(src, self.JL, self.goff[g.name], st.x_last, g.L, 0, nrm.weight, gbuf["mean_e"], gbuf["rstd_e"],
-                                  None, st.dxa, st.top16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(), st.ln_ws, B, g.L, E)
+                nrm, Lb = st.t.norm, self.Lb[g.name]  # noqa: N806
+                hip.layernorm_bwd(src, self.JL, self.goff[g.name], st.x_last, Lb, 0, nrm.weight, gbuf["mean_e"], gbuf["rstd_e"],
+                                  None, st.dxa, st.top16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(), st.ln_ws, B, Lb, E)
                 dx0, _ = st.backward(st.dxa, defer=defer)
-                dxg = dx0.view(B, g.L, E)
+                dxg = dx0.view(g.Beff, g.L, E)
                 for s in g.mods:
                     b = self.mb[s.name]
                     pe = b["pe"]
-                    T = B * s.n_tok  # noqa: N806
+                    T = s.Beff * s.n_tok  # noqa: N806
                     hip.embed_finish_bwd(dxg, b["yconv"], b["gn_stats"], pe.norm.weight, b["dyc"], ps.g(pe.norm.weight),
-                                         ps.g(pe.norm.bias), b["gn_sums"], B, s.D, s.L, E, s.tok_off, g.L)
+                                         ps.g(pe.norm.bias), b["gn_sums"], s.Beff, s.D, s.L, E, s.tok_off, g.L)
                     b["dw_conv"].zero_()
                     hip.gemm(hip.GEMM_TN, E, s.Kpad, T, b["dyc"], E, b["cols"], s.Kpad, b["dw_conv"], s.Kpad, AT)
                     hip.unpack_rows_add(b["dw_conv"], ps.g(pe.conv.weight), E, s.K, s.Kpad)

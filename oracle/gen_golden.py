@@ -196,6 +196,16 @@ def sup_case_table():
             dataset="pastis_hd", ds_kwargs=dict(filter_inputs=["s2", "s1_asc"], filter_targets=["pastis_seg", "pastis_mlc"]),
             mods=dict(), size="tiny", model_kw=dict(depth=2), inter_depth=1, fusion="group", type_head="attentive",
             B=2, seed=34),
+        # dates folded into the batch (utils.py:26-37): ONE encoder for every modality and date / one per modality;
+        # the heads still see [B, sum(dates) * L] tokens (segmentation: every date's grid resized to the reference grid)
+        "sup_flair_shared": dict(
+            dataset="flair", ds_kwargs=dict(filter_inputs=["aerial", "s2"], filter_targets=["cosia"], crop_meters=51.2),
+            mods=dict(aerial=dict(image_size=64, patch=16, bands=[[3, 0, 1, 2]], norm_bands=[1, 3], norm_fac=255.0)),
+            size="tiny", model_kw=dict(depth=2), inter_depth=0, fusion="shared", type_head="attentive", B=2, seed=35),
+        "sup_treesat_monotemp": dict(
+            dataset="treesatai_ts", ds_kwargs=dict(filter_targets=["treesat_mlc_thresh"]),
+            mods=dict(aerial=dict(image_size=60, patch=20, bands=4, norm_bands=[1, 3], norm_fac=255.0)),
+            size="tiny", model_kw=dict(depth=2), inter_depth=0, fusion="monotemp", type_head="attentive", B=2, seed=36),
     }
 
 
@@ -500,13 +510,16 @@ def main() -> None:
     ref = import_reference()
     GOLDEN.mkdir(parents=True, exist_ok=True)
     meta = dict(torch=torch.__version__, threads=torch.get_num_threads())
-    which = sys.argv[1] if len(sys.argv) > 1 else "all"      # all | pretrain | sup
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"      # all | pretrain | sup [case,case…]
     if which in ("all", "pretrain"):
         np.savez_compressed(GOLDEN / "layers.npz", **layer_vectors(ref))
         for name, case in case_table().items():
             out = run_case(name, case, ref, ours)
             np.savez_compressed(GOLDEN / f"{name}.npz", torch_version=np.array(meta["torch"]), **out)
+    only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None   # optional: comma-separated case names
     for name, case in (sup_case_table().items() if which in ("all", "sup") else ()):
+        if only is not None and name not in only:
+            continue
         out = run_sup_case(name, case, ref, ours)
         np.savez_compressed(GOLDEN / f"{name}.npz", torch_version=np.array(meta["torch"]), **out)
     pyc = [p for p in REFERENCE.rglob("__pycache__")]
