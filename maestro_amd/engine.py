@@ -83,6 +83,36 @@ class ParamStore:
     def mark_synced(self) -> None:
         self._version = self.flat._version
 
+    def flat_from(self, other: nn.Module, own: nn.Module) -> torch.Tensor:
+        """A flat fp32 GPU buffer in THIS store's layout holding the parameters of ``other``, a structural copy of the
+        module ``own`` whose parameters live here (e.g. the CPU-resident EMA model, ``train/base.py:267-274``)."""
+        theirs = dict(other.named_parameters())
+        out = torch.zeros_like(self.flat)
+        seen = set()
+        for name, p in own.named_parameters():
+            if id(p) in self.offset and id(p) not in seen:
+                seen.add(id(p))
+                o = self.offset[id(p)]
+                out[o: o + p.numel()].copy_(theirs[name].detach().reshape(-1), non_blocking=False)
+        return out
+
+    @contextlib.contextmanager
+    def swapped(self, other_flat: torch.Tensor, repack=None):
+        """Temporarily run with another set of parameter values (same layout): swap in, refresh the bf16 shadow, yield,
+        swap back.  Three passes over the flat buffer per use -- meant for evaluation steps, not the training loop."""
+        keep = self.flat.clone()
+        self.flat.copy_(other_flat)
+        self.refresh_half(force=True)
+        if repack is not None:
+            repack()
+        try:
+            yield
+        finally:
+            self.flat.copy_(keep)
+            self.refresh_half(force=True)
+            if repack is not None:
+                repack()
+
 
 # ======================================================================================= transformer stack
 class Stack:

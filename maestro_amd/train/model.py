@@ -239,15 +239,27 @@ class SSLModule(_Base):
         return log_inputs, log_preds, log_targets
 
     def probe_or_finetune_step(self, batch: dict, stage: str) -> dict:
-        """``base.py:185-224``.  (Evaluating the CPU-resident EMA copy at val/test time is host orchestration: load its
-        state dict into ``self.model`` before evaluating.)"""
+        """``base.py:185-224``: finetune evaluates (val / test) with the EMA weights when ``use_ema`` is on.  The EMA copy
+        stays on the CPU as in the reference; its values are gathered into a flat GPU buffer in the engine's layout (cached
+        until ``update_ema`` / a state-dict load changes them) and swapped in around the engine forward."""
         phase = self._ssl_phase()
         first = next(iter(self.dataset.inputs))
         engine = self.model.sup_engine(batch[first].shape[0], batch[first].device, phase)
-        engine.forward(batch)
+        if phase == "finetune" and stage != "train" and self.ema_model is not None:
+            with engine.store.swapped(self._ema_flat(engine), engine._pack_conv_weights):
+                engine.forward(batch)     # same stream as the swap copies: ordered without a host sync
+        else:
+            engine.forward(batch)
         loss = self.compute_loss_pred(engine, stage)
         log_inputs, log_preds, log_targets = self.compute_logs_pred(batch, engine, phase, stage)
         return {"loss": loss, "log_inputs": log_inputs, "log_preds": log_preds, "log_targets": log_targets}
+
+    def _ema_flat(self, engine) -> torch.Tensor:
+        version = sum(p._version for p in self.ema_model.parameters())
+        cache = getattr(self, "_ema_cache", None)
+        if cache is None or cache[0] is not engine.store or cache[1] != version:
+            cache = self._ema_cache = (engine.store, version, engine.store.flat_from(self.ema_model, self.model))
+        return cache[2]
 
     def shared_step(self, batch: dict, stage: str) -> dict:
         phase = self._ssl_phase()
@@ -275,3 +287,4 @@ class SSLModule(_Base):
         momentum = 1 - 1 / (self.trainer.max_epochs * 0.2)
         for p, pe in zip(self.model.parameters(), self.ema_model.parameters()):
             pe.data.mul_(momentum).add_((1.0 - momentum) * p.detach().data.to(pe.device))
+        self._ema_cache = None   # `.data` updates do not bump the version counters `_ema_flat` keys on

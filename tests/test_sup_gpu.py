@@ -134,3 +134,46 @@ def test_ssl_module_supervised_step_and_loop(phase):
     assert losses[-1] < 0.8 * losses[0], losses
     moved = [float((named[k].detach() - before[k]).abs().max()) for k in before]
     assert (max(moved) == 0.0) if phase == "probe" else (min(moved) > 0.0)
+
+
+def test_finetune_validation_uses_ema_weights():
+    """``base.py:195-202``: in finetune, val / test steps run the EMA model.  The EMA copy stays on the CPU; its values
+    are swapped into the engine's flat buffer around the forward and the trained weights are back afterwards."""
+    from types import SimpleNamespace
+
+    from maestro_amd.train.model import SSLModule
+    from oracle.gen_golden import build_datasets, make_batch, make_targets
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    DEV = torch.device("cuda:0")  # noqa: N806
+    case = CASES["sup_treesat_mlc"]
+    ds = build_datasets(case, conf)
+    batch = make_batch(ds.dataset, 4, 1)
+    batch.update(make_targets(ds.dataset, 4, 1))
+    torch.manual_seed(3)
+    module = SSLModule(datasets=ds, mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=1,
+                       model="mae", model_size="tiny", type_head="attentive", use_ema=True)
+    module.trainer = SimpleNamespace(ssl_phase="finetune", max_epochs=10)
+    dbatch = {k: v.to(DEV) for k, v in batch.items()}
+    train_loss = module.training_step(dbatch, 0)["loss"].item()
+    val_same = module.validation_step(dbatch, 0)["loss"].item()         # EMA == model right after construction
+    assert abs(val_same - train_loss) <= 1e-5 * abs(train_loss)
+    with torch.no_grad():                                                # make the EMA copy differ, the way update_ema would
+        for p in module.ema_model.parameters():
+            p.mul_(0.5)
+    eng = module.model._sup_engine
+    before = eng.store.flat.clone()
+    val_ema = module.validation_step(dbatch, 0)["loss"].item()
+    assert abs(val_ema - train_loss) > 1e-4 * abs(train_loss), "validation did not see the EMA weights"
+    assert torch.equal(eng.store.flat, before), "the trained weights must be back after the EMA evaluation"
+    assert abs(module.training_step(dbatch, 1)["loss"].item() - train_loss) <= 1e-5 * abs(train_loss)
+    # oracle check of the EMA forward: load the halved weights into a plain module and compare the loss
+    module2 = SSLModule(datasets=ds, mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=1,
+                        model="mae", model_size="tiny", type_head="attentive", use_ema=False)
+    module2.model.load_state_dict(module.ema_model.state_dict())
+    module2.trainer = SimpleNamespace(ssl_phase="finetune", max_epochs=10)
+    want = module2.validation_step(dbatch, 0)["loss"].item()
+    assert abs(val_ema - want) <= 1e-5 * abs(want), (val_ema, want)
+    module.update_ema()                                                  # invalidates the cached flat copy
+    assert module._ema_cache is None
+    del case
