@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import time
 
 import torch
 from torch import nn
@@ -401,6 +402,7 @@ class MAEEngine(EngineBase):
             raise ValueError(f"MAESTRO_WGRAD={self.wgrad_mode!r}: expected auto, fused or deferred")
         self._wgrad_tables, self._wgrad_plans, self._zero_lists = {}, {}, {}
         self._h2d_done = [None] * RING   # per ring slot: event after the mask uploads that last used it
+        self.host_wait_s = 0.0           # time the host spent blocked on that ring (diagnostic: not issue work)
         self._step = 0
         self._enc_state = {}        # per group: (grad f32, grad bf16) carried between encoder backward segments
         B = batch_size  # noqa: N806
@@ -508,7 +510,9 @@ class MAEEngine(EngineBase):
         slot = self._step % RING
         self._step += 1
         if self._h2d_done[slot] is not None:
-            self._h2d_done[slot].synchronize()
+            t0 = time.perf_counter()
+            self._h2d_done[slot].synchronize()   # back-pressure: only blocks when the host runs >= RING steps ahead
+            self.host_wait_s += time.perf_counter() - t0
         for g in self.groups:
             gbuf = self.gb[g.name]
             nh, sh = gbuf["noise_h"][slot], gbuf["struct_h"][slot]
