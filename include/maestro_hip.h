@@ -244,6 +244,11 @@ int mh_unpack_rows_add(const float* src, float* dst, int E, int K, int Kpad, voi
  * n % 4 == 0, step >= 1. */
 int mh_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float b1, float b2,
              float eps, float wd, int step, float grad_scale, void* stream);
+/* The same update with the per-step scalars read from DEVICE memory, so that the launch can sit inside a captured hipGraph
+ * (the optimizer step overlapped with the next forward): hyper = f32 [5] = {lr, 1 - b1^step, sqrt(1 - b2^step), grad_scale,
+ * active}; active == 0 makes the launch a no-op (no update pending). */
+int mh_adamw_dev(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float b1, float b2, float eps,
+                 float wd, const float* hyper, void* stream);
 
 #ifdef __cplusplus
 }

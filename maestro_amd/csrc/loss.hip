@@ -114,9 +114,9 @@ __global__ __launch_bounds__(256) void unpack_rows_add_kernel(const float* __res
 }
 
 // torch.optim.AdamW step (decoupled weight decay, bias correction), 4 elements per thread, grid-stride free.
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr, float b1,
-                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+__device__ __forceinline__ void adamw_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                             float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr, float b1, float b2,
+                                             float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i) * gscale;
@@ -138,6 +138,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         u32x2 pk = {pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3])};
         *reinterpret_cast<u32x2*>(pb + i) = pk;
     }
+}
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    adamw_update(p, g, m, v, pb, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+}
+// per-step scalars from device memory: the launch is captured once and replayed with new values (see mh_adamw_dev)
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, bf16_t* __restrict__ pb, long n, float b1, float b2,
+                                                        float eps, float wd, const float* __restrict__ hyper) {
+    if (hyper[4] == 0.f) return;
+    adamw_update(p, g, m, v, pb, n, hyper[0], b1, b2, eps, wd, hyper[1], hyper[2], hyper[3]);
 }
 
 }  // namespace
@@ -201,6 +213,15 @@ extern "C" int mh_adamw(float* p, const float* g, float* m, float* v, void* p_bf
     const float bc2_sqrt = sqrtf(1.f - powf(b2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n, lr,
                        b1, b2, eps, wd, bc1, bc2_sqrt, grad_scale);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_adamw_dev(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float b1, float b2, float eps,
+                            float wd, const float* hyper, void* stream) {
+    MH_CHECK_ARG(p && g && m && v && hyper && n > 0 && n % 4 == 0, "mh_adamw_dev: bad arguments (n %% 4 == 0)");
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16,
+                       n, b1, b2, eps, wd, hyper);
     MH_LAUNCH_CHECK();
     return 0;
 }

@@ -165,10 +165,13 @@ class Stack:
         """Gradient slot of the last layer's fc2 bias: it equals colsum(d x_last), produced by the final-LN backward."""
         return self.eng.store.g(self.t.layers[-1][1].net[4].bias) if self.depth else None
 
-    def forward(self) -> None:
+    def forward(self, before_layer=None) -> None:
+        """``before_layer(l)``: called ahead of layer l's first launch (the overlapped optimizer's per-layer wait)."""
         eng, ps, M = self.eng, self.eng.store, self.M  # noqa: N806
         dim, mlp, inner = self.dim, self.mlp, self.inner
         for l, (attn, ff) in enumerate(self.t.layers):
+            if before_layer is not None:
+                before_layer(l)
             s, x_in, x_mid, x_out = self.saved[l], self.xs[2 * l], self.xs[2 * l + 1], self.xs[2 * l + 2]
             hip.layernorm_fwd(x_in, M, 0, attn.norm.weight, attn.norm.bias, s["h1"], M, 0, s["mean1"], s["rstd1"], 1, M, dim)
             hip.gemm(hip.GEMM_NT, M, 3 * inner, dim, s["h1"], dim, ps.h(attn.to_qkv.weight), dim, s["qkv"], 3 * inner)
@@ -402,6 +405,7 @@ class MAEEngine(EngineBase):
             raise ValueError(f"MAESTRO_WGRAD={self.wgrad_mode!r}: expected auto, fused or deferred")
         self._wgrad_tables, self._wgrad_plans, self._zero_lists = {}, {}, {}
         self._h2d_done = [None] * RING   # per ring slot: event after the mask uploads that last used it
+        self._opt = None                 # overlapped optimizer (attach_optimizer)
         self.host_wait_s = 0.0           # time the host spent blocked on that ring (diagnostic: not issue work)
         self._step = 0
         self._enc_state = {}        # per group: (grad f32, grad bf16) carried between encoder backward segments
@@ -520,6 +524,11 @@ class MAEEngine(EngineBase):
             sh.copy_(struct[g.name].reshape(g.Beff, g.L))
             gbuf["noise"].copy_(nh, non_blocking=True)
             gbuf["struct"].copy_(sh, non_blocking=True)
+        if self._opt is not None:      # overlapped optimizer: this step's scalars (or "nothing pending") ride the same ring
+            hh = self._opt_hyper_h[slot]
+            hh.copy_(torch.tensor(self._opt_pending if self._opt_pending is not None else [0.0] * 5, dtype=F32))
+            self._opt_hyper.copy_(hh, non_blocking=True)
+            self._opt_pending = None
         ev = torch.cuda.Event()
         ev.record()
         self._h2d_done[slot] = ev
@@ -546,17 +555,114 @@ class MAEEngine(EngineBase):
         self._staged = batch
         key = self._cur_key = tuple(batch[k].data_ptr() for k in sorted(batch) if isinstance(batch[k], torch.Tensor))
         with self._tuning_pass("forward"):
-            self._segment("forward", key, lambda: self._forward_launches(batch))
+            self._segment("forward" if self._opt is None else "forward:opt", key, lambda: self._forward_launches(batch))
+        if self._opt is not None:
+            self.store.mark_synced()   # the optimizer stages inside the forward refreshed the bf16 shadows themselves
         return self.loss_acc
+
+    # ------------------------------------------------------------------------------------------ overlapped optimizer
+    def attach_optimizer(self, opt) -> None:
+        """Run ``opt``'s AdamW update of step t INSIDE the forward of step t+1 (``defer_step`` queues it): the update is
+        HBM-bound, the forward MFMA-bound, so on a side stream it hides under the GEMMs.  The flat buffer is cut into
+        stages in the order the forward needs the parameters (patch embed, encoder layer 0 of every group, layer 1, ...,
+        joint layers, enc_to_dec + mask tokens, decoder layers, pixelify); every stage is one or a few ``mh_adamw_dev``
+        launches followed by an event that the consuming stream waits for right before the first kernel that reads those
+        parameters.  The per-step scalars live in device memory, so the whole thing is captured into the forward hipGraph."""
+        m, ps = self.model, self.store
+        if (opt.lo, opt.hi) != (0, ps.total):
+            raise ValueError("the overlapped optimizer expects an optimizer over the whole flat buffer")
+        stages: dict = {}
+
+        def add(key, params):
+            params = list(params)
+            if params:
+                stages.setdefault(key, []).append(ps.span(params))
+
+        for name in m.patch_embed:
+            add(("embed", 0), m.patch_embed[name].parameters())
+        for kind, holders in (("enc", [m.encoder[n] for n in m.encoder]),
+                              ("joint", [m.encoder_inter] if m.encoder_inter is not None else []),
+                              ("dec", [m.decoder[n] for n in m.decoder])):
+            for t in holders:
+                depth = len(t.layers)
+                for l, layer in enumerate(t.layers):
+                    add((kind, l), layer.parameters())
+                add((kind, max(depth - 1, 0)), t.norm.parameters())   # the final LN is read after the last layer
+        add(("e2d", 0), [p for n in m.enc_to_dec for p in m.enc_to_dec[n].parameters()] + list(m.mask_token.values()))
+        for name in m.embed_to_rec:
+            add(("rec", 0), m.embed_to_rec[name].parameters())
+        order = {"embed": 0, "enc": 1, "joint": 2, "e2d": 3, "dec": 4, "rec": 5}
+        self._opt_stage_keys = sorted(stages, key=lambda k: (order[k[0]], k[1]))
+        covered = sorted(sp for k in stages for sp in stages[k])
+        assert covered[0][0] == 0 and all(a[1] <= b[0] for a, b in zip(covered, covered[1:])), "optimizer stages overlap"
+        n_cov = sum(hi - lo for lo, hi in covered)
+        n_par = sum((p.numel() + ALIGN - 1) // ALIGN * ALIGN for p in ps.params)
+        assert n_cov >= n_par - ALIGN * len(ps.params) and covered[-1][1] <= ps.total, "optimizer stages miss parameters"
+        self._opt_stages = stages
+        self._opt = opt
+        self._opt_hyper = torch.zeros(5, dtype=F32, device=self.device)
+        self._opt_hyper_h = [torch.zeros(5, dtype=F32).pin_memory() for _ in range(RING)]
+        self._opt_pending = None
+        self._opt_events = {}
+        self._opt_stream = torch.cuda.Stream(device=self.device)
+
+    def defer_step(self, lr: float, grad_scale: float = 1.0) -> None:
+        """Queue the optimizer update of the gradients now in the flat buffer; it runs inside the next ``forward``."""
+        opt = self._opt
+        if self._opt_pending is not None:
+            raise RuntimeError("an optimizer update is already pending: call forward() or flush_optimizer() first")
+        opt.t += 1
+        bc1, bc2_sqrt = hip.adamw_bias_corrections(opt.betas[0], opt.betas[1], opt.t)
+        self._opt_pending = [lr, bc1, bc2_sqrt, grad_scale, 1.0]
+
+    def flush_optimizer(self) -> None:
+        """Apply a pending update now (end of training, before a checkpoint / evaluation reads the parameters)."""
+        if self._opt is None or self._opt_pending is None:
+            return
+        lr, _, _, scale, _ = self._opt_pending
+        self._opt_pending = None
+        self._opt.t -= 1               # FusedAdamW.step counts the step itself
+        self._opt.step(lr=lr, grad_scale=scale)
+
+    def _opt_launch_stages(self) -> None:
+        """Issue every optimizer stage (on the side stream when streams are on) and record one event per stage."""
+        opt, ps = self._opt, self.store
+        main = torch.cuda.current_stream()
+        side = self._opt_stream if self.multi_stream else main
+        if side is not main:
+            side.wait_stream(main)
+        self._opt_events = {}
+        with torch.cuda.stream(side):
+            for key in self._opt_stage_keys:
+                for lo, hi in self._opt_stages[key]:
+                    hip.adamw_dev(ps.flat[lo:hi], ps.grad[lo:hi], opt.m[lo:hi], opt.v[lo:hi], ps.half[lo:hi], hi - lo,
+                                  opt.betas[0], opt.betas[1], opt.eps, opt.wd, self._opt_hyper)
+                if key[0] == "embed":
+                    self._pack_conv_weights()   # patch-embed weights also live in a K-padded bf16 layout
+                if side is not main:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    self._opt_events[key] = ev
+
+    def _opt_wait(self, kind: str, l: int = 0) -> None:
+        """Make the current stream wait for the optimizer stage that owns (kind, layer l) parameters."""
+        if self._opt is None:
+            return
+        ev = self._opt_events.get((kind, l))
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def _forward_launches(self, batch: dict) -> None:
         m, E, Dd = self.model, self.E, self.Dd  # noqa: N806
         self.loss_acc.zero_()
         ref_date = batch["ref_date"]
+        if self._opt is not None:
+            self._opt_launch_stages()
 
         def head(g):
             def run():
                 gbuf, st = self.gb[g.name], self.enc[g.name]
+                self._opt_wait("embed")
                 # ---- embed: patchify -> conv GEMM -> GroupNorm + encodings into the group sequence
                 for s in g.mods:
                     b = self.mb[s.name]
@@ -581,8 +687,9 @@ class MAEEngine(EngineBase):
                 hip.mask_select(gbuf["noise"], gbuf["struct"], gbuf["vis"], gbuf["msk"], gbuf["inv"], gbuf["mask"], g.Beff,
                                 g.L, g.k)
                 hip.gather_rows(gbuf["xg"], gbuf["vis"], st.x0, g.Beff, g.L, g.N, E, g.N, 0)
-                st.forward()
+                st.forward(lambda l: self._opt_wait("enc", l))
                 nrm = st.t.norm
+                self._opt_wait("enc", max(st.depth - 1, 0))
                 if self.joint is not None:
                     hip.layernorm_fwd(st.x_last, g.N, 0, nrm.weight, nrm.bias, self.joint.x0, m.joint_N, g.joint_off,
                                       gbuf["mean_e"], gbuf["rstd_e"], g.Beff, g.N, E)
@@ -594,6 +701,7 @@ class MAEEngine(EngineBase):
         def tail(g):
             def run():
                 gbuf, st = self.gb[g.name], self.dec[g.name]
+                self._opt_wait("e2d")
                 if self.joint is not None:
                     nrm = self.joint.t.norm
                     hip.layernorm_fwd(self.joint.x_last, m.joint_N, g.joint_off, nrm.weight, nrm.bias, gbuf["henc"], g.N, 0,
@@ -606,8 +714,9 @@ class MAEEngine(EngineBase):
                     gbuf["tok_table"][s.slot].copy_(m.mask_token[s.name].view(-1))
                 hip.unmask_assemble(gbuf["y_e2d"], gbuf["inv"], gbuf["tok_table"], gbuf["tok_slot"], gbuf["pos_dec"],
                                     gbuf["dates"], gbuf["date_row"], gbuf["n_dates"], st.x0, g.Beff, g.L, g.N, Dd)
-                st.forward()
+                st.forward(lambda l: self._opt_wait("dec", l))
                 nrm = st.t.norm
+                self._opt_wait("rec")
                 for s in g.mods:
                     b = self.mb[s.name]
                     T = s.Beff * s.n_tok  # noqa: N806
@@ -623,8 +732,10 @@ class MAEEngine(EngineBase):
 
         self._run_parallel([head(g) for g in self.groups])
         if self.joint is not None:
-            self.joint.forward()
+            self.joint.forward(lambda l: self._opt_wait("joint", l))
         self._run_parallel([tail(g) for g in self.groups])
+        if self._opt is not None and self._opt_events:
+            torch.cuda.current_stream().wait_stream(self._opt_stream)   # join (a capture must end with every fork joined)
 
     # ------------------------------------------------------------------------------------------ backward
     def zero_grad(self) -> None:

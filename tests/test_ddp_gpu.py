@@ -47,6 +47,7 @@ def _worker(rank, world, port, out):
     same_grad = all(torch.equal(gathered[0], g) for g in gathered)
     for _ in range(3):
         loop.step(batch)
+    loop.flush()                                            # the last update is queued for the next forward
     torch.cuda.synchronize()
     flat = eng.store.flat.cpu()
     allp = [torch.zeros_like(flat) for _ in range(world)]

@@ -342,3 +342,45 @@ def test_gradient_accumulation_sums_micro_batches():
     eng.forward(mbs[1]); eng.zero_grad(); eng.backward(); g1 = st.grad.clone()
     rel = ((seen["g"] - (g0 + g1)).norm() / (g0 + g1).norm()).item()
     assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("fusion,inter", [("group", 1), ("shared", 0)])
+def test_optimizer_overlapped_with_next_forward_matches_classic_step(fusion, inter):
+    """``PretrainLoop(overlap_optimizer=True)`` queues AdamW of step t and runs it, cut into per-layer stages on a side
+    stream, inside the (captured) forward of step t+1.  Same arithmetic, same order per element: after ``flush()`` the
+    parameters, the optimizer moments and every step's loss equal the classic end-of-step update."""
+    from maestro_amd.train.trainer import PretrainLoop, synthetic_batch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    ds = conf.DatasetsConfig(name_dataset="treesatai_ts", treesatai_ts=conf.TreeSatAITSConfig(
+        filter_targets=[], aerial=conf.InputRasterConfig(image_size=60, patch_size=conf.PatchSizeConfig(mae=20), bands=4,
+                                                         norm_bands=[1, 3], norm_fac=255.0)))
+    batch = synthetic_batch(ds.dataset, 2, dev, seed=3)
+    runs = {}
+    for overlap in (False, True, "again"):      # "again": the classic step a second time = the run-to-run noise floor
+        key, overlap = overlap, overlap is True
+        torch.manual_seed(0)
+        model = pmae.mae_tiny(datasets=ds, mask=conf.MaskConfig(), depth=3, inter_depth=inter, fusion_mode=fusion,
+                              **{k: v for k, v in COMMON.items()})
+        loop = PretrainLoop(model, 2, dev, loss="l2_norm", base_lr=3e-3, total_steps=12, overlap_optimizer=overlap)
+        torch.manual_seed(7)
+        losses = [loop.step(batch).item() for _ in range(6)]   # eager, eager, capture, replays
+        if overlap:
+            assert loop.engine._opt_pending is not None and "forward:opt" in loop.engine._graphs
+        loop.flush()
+        torch.cuda.synchronize()
+        runs[key] = (losses, loop.engine.store.flat.clone(), loop.opt.m.clone(), loop.opt.v.clone(), loop.opt.t,
+                     loop.engine.store.half.float().clone())
+    (l0, p0, m0, v0, t0, h0), (l1, p1, m1, v1, t1, h1), (l2, p2, m2, v2, _, _) = runs[False], runs[True], runs["again"]
+    assert t0 == t1 == 6
+    assert l0[0] != l0[-1]
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-4 * abs(a), (l0, l1)
+    # Atomic accumulation orders differ from run to run, and Adam turns a sign flip of a near-zero gradient into a full
+    # +-lr step: the bar is the classic step's own run-to-run spread, not zero.
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()  # noqa: E731
+    noise_p, noise_m, noise_v = rel(p2, p0), rel(m2, m0), rel(v2, v0)
+    assert rel(p1, p0) <= 10.0 * noise_p + 1e-7, (rel(p1, p0), noise_p)
+    assert rel(m1, m0) <= 10.0 * noise_m + 1e-7 and rel(v1, v0) <= 10.0 * noise_v + 1e-7, (rel(m1, m0), noise_m, rel(v1, v0), noise_v)
+    assert torch.equal(h1, p1.bfloat16().float()), "bf16 shadow out of date after the overlapped update"
