@@ -90,3 +90,49 @@ def test_every_baseline_config_runs(config, B):
     pixels, masks = eng.reconstructions()
     for m, c in ds.dataset.inputs.items():
         assert pixels[m].shape == batch[m].shape and masks[m].shape == batch[m].shape and masks[m].dtype == torch.bool
+
+
+@pytest.mark.parametrize("config,phase", [("c3", "finetune"), ("c3", "probe"), ("c4", "finetune")])
+def test_supervised_full_size_properties(config, phase):
+    """The probe / finetune branch at the full BASELINE shapes (C3: FLAIR segmentation, 15 classes at 512 x 512 on top of
+    1424 tokens per tile; C4: ViT-L multilabel): finite loss and gradients, probe leaves the encoder's gradient slice
+    untouched, the loss starts near ln(classes) / ln 2 for random heads, and a few AdamW steps on a fixed batch lower it."""
+    import math
+
+    import bench
+    from maestro_amd.train.trainer import SupervisedLoop, synthetic_batch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    B = 2
+    torch.manual_seed(0)
+    ds, model = bench.build_model(config, phase)
+    loop = SupervisedLoop(model, B, dev, phase=phase, base_lr=1e-3, total_steps=20)
+    batch = synthetic_batch(ds.dataset, B, dev)
+    batch.update(bench.synthetic_targets(ds.dataset, B, dev))
+    eng = loop.engine
+    first = eng.forward(batch).item()
+    n_cls = {t: c.num_classes for t, c in ds.dataset.targets.items()}
+    kinds = {c.type_target for c in ds.dataset.targets.values()}
+    expect = sum(math.log(n) if ds.dataset.targets[t].type_target != "multilabel_classif" else math.log(2.0)
+                 for t, n in n_cls.items())
+    assert math.isfinite(first) and 0.3 * expect < first < 3.0 * expect, (first, expect, kinds)
+    eng.zero_grad()
+    eng.backward()
+    torch.cuda.synchronize()
+    g = eng.store.grad
+    assert torch.isfinite(g).all()
+    lo, hi = eng.trainable_span
+    assert float(g[lo:hi].abs().sum()) > 0
+    if phase == "probe":
+        assert lo > 0 and float(g[:lo].abs().sum()) == 0.0
+    else:
+        assert lo == 0 and float(g[: g.numel() // 2].abs().sum()) > 0
+    losses = [float(loop.step(batch)) for _ in range(8)]
+    assert all(math.isfinite(x) for x in losses) and losses[-1] < losses[0], losses
+    logits = eng.logits()
+    for t, c in ds.dataset.targets.items():
+        if c.type_target == "segment":
+            assert logits[t].shape[0] == B and logits[t].shape[-3] == c.num_classes
+        else:
+            assert tuple(logits[t].shape) == (B, c.num_classes)
