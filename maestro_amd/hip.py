@@ -342,13 +342,19 @@ def adamw(p, g, m, v, p_bf16, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
     call("mh_adamw", p, g, m, v, p_bf16, _L(n), _F(lr), _F(b1), _F(b2), _F(eps), _F(wd), _I(step), _F(grad_scale))
 
 
+_libm = None
+
+
 def adamw_bias_corrections(b1: float, b2: float, step: int) -> tuple[float, float]:
     """``(1 - b1^t, sqrt(1 - b2^t))`` in the float32 arithmetic ``mh_adamw`` uses on the host (libm ``powf``), so that the
     device-scalar variant applies bit-identical updates."""
     import numpy as np
-    libm = ctypes.CDLL("libm.so.6")
-    libm.powf.restype = ctypes.c_float
-    libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    global _libm
+    if _libm is None:
+        _libm = ctypes.CDLL("libm.so.6")
+        _libm.powf.restype = ctypes.c_float
+        _libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    libm = _libm
     f = np.float32
     bc1 = f(1.0) - f(libm.powf(float(f(b1)), float(step)))
     bc2 = np.sqrt(f(1.0) - f(libm.powf(float(f(b2)), float(step))), dtype=np.float32)
