@@ -377,10 +377,12 @@ def test_optimizer_overlapped_with_next_forward_matches_classic_step(fusion, int
     assert l0[0] != l0[-1]
     for a, b in zip(l0, l1):
         assert abs(a - b) <= 2e-4 * abs(a), (l0, l1)
-    # Atomic accumulation orders differ from run to run, and Adam turns a sign flip of a near-zero gradient into a full
-    # +-lr step: the bar is the classic step's own run-to-run spread, not zero.
+    # Same arithmetic per element (bias corrections included), so the only difference is the run-to-run order of the atomic
+    # gradient sums, which Adam amplifies (a sign flip of a near-zero gradient is a full +-lr step): typically 1e-9..1e-7
+    # after six steps (up to 5e-5 when the split-K weight-gradient path is active), also between two classic runs.  A wrong stage / scalar shows up at >= 1e-3.
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()  # noqa: E731
-    noise_p, noise_m, noise_v = rel(p2, p0), rel(m2, m0), rel(v2, v0)
-    assert rel(p1, p0) <= 10.0 * noise_p + 1e-7, (rel(p1, p0), noise_p)
-    assert rel(m1, m0) <= 10.0 * noise_m + 1e-7 and rel(v1, v0) <= 10.0 * noise_v + 1e-7, (rel(m1, m0), noise_m, rel(v1, v0), noise_v)
+    noise = (rel(p2, p0), rel(m2, m0), rel(v2, v0))
+    got = (rel(p1, p0), rel(m1, m0), rel(v1, v0))
+    for g, n, floor in zip(got, noise, (2e-5, 2e-4, 2e-4)):   # the bar is the larger of a fixed floor and the measured spread
+        assert g < max(floor, 3.0 * n), (got, noise)
     assert torch.equal(h1, p1.bfloat16().float()), "bf16 shadow out of date after the overlapped update"
