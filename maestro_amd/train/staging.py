@@ -41,8 +41,11 @@ class BatchStager:
         self._n = 0
 
     def _pin(self, slot: int, key: str, t: torch.Tensor) -> torch.Tensor:
+        if t.is_pinned():      # a DataLoader(pin_memory=True) batch: copy straight from it, keep it alive with the slot
+            self._pinned[slot][key] = t
+            return t
         buf = self._pinned[slot].get(key)
-        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype or buf is t:
             buf = self._pinned[slot][key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
         buf.copy_(t)
         return buf
