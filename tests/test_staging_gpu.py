@@ -54,3 +54,28 @@ def test_stager_matches_reference_draw_order():
     assert torch.equal(out["label"].cpu(), batch["label"]) and out["aerial_dates"].dtype == torch.int16
     plain = stager.stage(batch, None)
     assert torch.equal(plain["aerial"].cpu(), batch["aerial"])
+
+
+def test_stager_copies_pinned_loader_batches_in_place():
+    """A DataLoader(pin_memory=True) batch is DMA-ed straight from the loader's pinned tensors (no extra host copy); a
+    pageable batch goes through the stager's own pinned ring.  Both give the same device tensors."""
+    from maestro_amd.train.staging import BatchStager
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(4, 2, 3, 16, 16, generator=g)
+    dates = torch.randint(0, 300, (4, 2, 3), generator=g).to(torch.int16)
+    flags = torch.tensor([0, 3, 4, 7], dtype=torch.uint8)
+    st = BatchStager(dev, rasters=["r"])
+    pageable = st.stage({"r": x, "r_dates": dates}, flags)
+    pinned_x = x.clone().pin_memory()
+    pinned = st.stage({"r": pinned_x, "r_dates": dates.clone().pin_memory()}, flags)
+    torch.cuda.synchronize()
+    assert st._pinned[1]["r"] is pinned_x                      # slot 1 holds the loader's tensor itself, not a copy
+    assert st._pinned[0]["r"] is not x and st._pinned[0]["r"].is_pinned()
+    assert torch.equal(pageable["r"], pinned["r"]) and torch.equal(pageable["r_dates"], pinned["r_dates"])
+    for b in range(4):
+        want = ost.transform_rasters({"r": x[b].numpy()}, int(flags[b]))["r"]
+        assert np.array_equal(pinned["r"][b].cpu().numpy(), want)
+    again = st.stage({"r": x, "r_dates": dates}, flags)          # slot 0 again: a pageable batch must not reuse a loader tensor
+    torch.cuda.synchronize()
+    assert torch.equal(again["r"], pageable["r"])
