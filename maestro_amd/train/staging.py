@@ -36,16 +36,18 @@ class BatchStager:
         hip.lib()
         self.device, self.rasters, self.depth = device, list(rasters), depth
         self.stream = torch.cuda.Stream(device=device)
-        self._pinned = [dict() for _ in range(depth)]
+        self._pinned = [dict() for _ in range(depth)]   # the stager's own pinned buffers, per ring slot
+        self._held = [dict() for _ in range(depth)]     # loader-owned pinned tensors kept alive until their copy is done
         self._done = [None] * depth
         self._n = 0
 
     def _pin(self, slot: int, key: str, t: torch.Tensor) -> torch.Tensor:
         if t.is_pinned():      # a DataLoader(pin_memory=True) batch: copy straight from it, keep it alive with the slot
-            self._pinned[slot][key] = t
+            self._held[slot][key] = t
             return t
+        self._held[slot].pop(key, None)
         buf = self._pinned[slot].get(key)
-        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype or buf is t:
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
             buf = self._pinned[slot][key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
         buf.copy_(t)
         return buf

@@ -70,12 +70,14 @@ def test_stager_copies_pinned_loader_batches_in_place():
     pinned_x = x.clone().pin_memory()
     pinned = st.stage({"r": pinned_x, "r_dates": dates.clone().pin_memory()}, flags)
     torch.cuda.synchronize()
-    assert st._pinned[1]["r"] is pinned_x                      # slot 1 holds the loader's tensor itself, not a copy
+    assert st._held[1]["r"] is pinned_x and "r" not in st._pinned[1]   # slot 1 holds the loader's tensor itself, no copy
     assert st._pinned[0]["r"] is not x and st._pinned[0]["r"].is_pinned()
     assert torch.equal(pageable["r"], pinned["r"]) and torch.equal(pageable["r_dates"], pinned["r_dates"])
     for b in range(4):
         want = ost.transform_rasters({"r": x[b].numpy()}, int(flags[b]))["r"]
         assert np.array_equal(pinned["r"][b].cpu().numpy(), want)
-    again = st.stage({"r": x, "r_dates": dates}, flags)          # slot 0 again: a pageable batch must not reuse a loader tensor
+    st.stage({"r": x, "r_dates": dates}, flags)                  # slot 0
+    other = torch.rand(4, 2, 3, 16, 16, generator=g)
+    again = st.stage({"r": other, "r_dates": dates}, None)       # slot 1 with a pageable batch: the loader's tensor is untouched
     torch.cuda.synchronize()
-    assert torch.equal(again["r"], pageable["r"])
+    assert torch.equal(pinned_x, x) and torch.equal(again["r"].cpu(), other) and "r" not in st._held[1]
