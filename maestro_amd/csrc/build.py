@@ -78,5 +78,23 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+EXAMPLE_SRC = ROOT / "examples" / "abi_smoke.cpp"
+EXAMPLE_BIN = ROOT / "examples" / "abi_smoke"
+
+
+def build_example(force: bool = False) -> Path:
+    """The plain C++ caller of the C ABI (no torch, no Python): linked against the in-tree library, found through an
+    $ORIGIN-relative rpath so that it runs from the repo snapshot on the GPU box."""
+    if not force and EXAMPLE_BIN.exists() and EXAMPLE_BIN.stat().st_mtime >= max(EXAMPLE_SRC.stat().st_mtime, LIB.stat().st_mtime):
+        return EXAMPLE_BIN
+    cmd = [_hipcc(), "-O2", "-std=c++17", f"--offload-arch={ARCH}", str(EXAMPLE_SRC), f"-I{ROOT / 'include'}", f"-L{LIB_DIR}",
+           "-lmaestro_hip", "-Wl,-rpath,$ORIGIN/../maestro_amd/lib", "-o", str(EXAMPLE_BIN)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"building examples/abi_smoke failed:\n{r.stdout}\n{r.stderr}")
+    return EXAMPLE_BIN
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_example(force="--force" in sys.argv))
