@@ -46,6 +46,7 @@ SUP_WORKLOADS = {
                ds=lambda: conf.DatasetsConfig(name_dataset="treesatai_ts", treesatai_ts=conf.TreeSatAITSConfig())),
 }
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_TBS = 8.0          # HBM3E, same guide
 
 
 def sup_gflop_per_tile(model, phase: str) -> float:
@@ -319,11 +320,16 @@ def main() -> None:
         if timer is not None:
             out["roofline"] = timer.roofline(MFMA_PEAK_TFLOPS)
             traffic_file = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-            if os.path.exists(traffic_file) and args.phase == "pretrain":  # PMC passes are separate runs (rocprofv3 --pmc); committed summary
+            # PMC passes are separate runs (rocprofv3 --pmc) of the DEFAULT workload: the committed summary applies to it only
+            if os.path.exists(traffic_file) and args.phase == "pretrain" and args.config == "c3" and args.batch == 32:
                 kern = json.load(open(traffic_file))["kernels"].get(out["roofline"]["kernel"])
                 if kern:
                     out["roofline"]["traffic"] = kern["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                whole = json.load(open(traffic_file)).get("hbm_bytes_per_step")
+                if whole:   # every kernel's PMC bytes per launch x launches per step: the step's second bound next to mfma_frac
+                    out["whole_step"]["hbm_gb_per_step"] = round(whole / 1e9, 1)
+                    out["whole_step"]["hbm_frac"] = round(whole / (elapsed / args.steps) / (HBM_PEAK_TBS * 1e12), 4)
             out["roofline"]["measured_over"] = f"{args.steps} eagerly launched single-stream steps right after the timed region"
             out["kernel_times_ms_per_step"] = timer.summary(args.steps)
         if timer is not None and args.shapes:

@@ -54,7 +54,10 @@ for k, v in agg.items():
     f, w = v["FETCH_SIZE_KB"] / v["launches"], v["WRITE_SIZE_KB"] / v["launches"]
     out[k] = {"launches_in_trace": v["launches"], "fetch_kb_per_launch_raw": round(f, 1), "write_kb_per_launch": round(w, 1),
               "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
-json.dump({"note": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE correction applied", "kernels": out},
+PMC_STEPS = 5   # profile_round.sh runs the counter passes with --steps 2 --warmup 3
+per_step = sum(v["hbm_bytes_per_launch"] * v["launches_in_trace"] for v in out.values()) / PMC_STEPS
+json.dump({"note": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE correction applied", "steps_in_trace": PMC_STEPS,
+           "hbm_bytes_per_step": int(per_step), "kernels": out},
           open(dst / f"{tag}_hbm_traffic.json", "w"), indent=1, sort_keys=True)
 rows = list(csv.DictReader(open(src / f"{tag}_kernel_stats.csv")))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
