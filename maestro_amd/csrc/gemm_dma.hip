@@ -31,6 +31,7 @@ struct Tile {
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;   // 1-KiB DMA pieces per wave and K step
     static constexpr int LDS_BYTES = S * STAGE_BYTES;
+    static constexpr int MIN_WG = NT >= 512 ? 1 : 512 / NT;   // workgroups per CU the register budget must allow (2 waves / SIMD)
     static_assert(BN >= 128, "the K-major swizzle needs at least 8 32-byte chunks per row");
     static_assert(PA * NW * 1024 == A_BYTES && PB * NW * 1024 == B_BYTES, "pieces must divide evenly over the waves");
     static_assert(LDS_BYTES >= NW * 32 * 68 * 4, "the ring doubles as epilogue staging");
@@ -164,7 +165,9 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
 }
 
 template <class T, bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(T::NT) void gemm_dma_kernel(GemmParams p) {
+// Second launch bound = workgroups per CU: without it the 128- and 256-thread tiles were given 304 VGPRs, i.e. ONE wave per
+// SIMD and one workgroup per CU instead of the two (four) their LDS footprint was sized for.
+__global__ __launch_bounds__(T::NT, T::MIN_WG) void gemm_dma_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[T::LDS_BYTES];  // the ONLY LDS object
     const int nwg = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nwg);
