@@ -43,6 +43,9 @@ int mh_version(void);
 #define MH_GEMM_ATOMIC 32
 #define MH_GEMM_COLSUM 64   /* bf16 output only: colsum[(m / 64), n] = sum over the 64-row block of C[m, n] (f32 values before
                              * rounding); colsum is a [ceil(M / 64), N] workspace, plain stores; reduce it with mh_colsum */
+#define MH_GEMM_AUX_DGELU 128 /* with MH_GEMM_GELU: aux_out receives GELU'(pre-activation) (bf16) instead of the pre-activation: the
+                               * CDF / PDF are already at hand in the forward epilogue, so the backward only multiplies */
+#define MH_GEMM_MULAUX 256    /* bf16 output only: C *= aux_in[M, N] (bf16) -- the backward of GELU with the saved derivative */
 int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                  int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                  int ldaux, float* colsum, void* stream);

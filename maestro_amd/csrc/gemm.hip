@@ -319,7 +319,7 @@ extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, cons
     MH_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0, "mh_gemm_bf16: N and ldc must be multiples of 4 (%d, %d)", N, ldc);
     MH_CHECK_ARG((flags & MH_GEMM_OUT_F32) || (N % 8 == 0 && ldc % 8 == 0), "mh_gemm_bf16: bf16 output needs N, ldc %% 8 == 0");
     MH_CHECK_ARG((flags & MH_GEMM_OUT_F32) || !(flags & MH_GEMM_RESIDUAL), "mh_gemm_bf16: residual epilogue needs f32 output");
-    MH_CHECK_ARG(!(flags & MH_GEMM_OUT_F32) || !(flags & (MH_GEMM_GELU | MH_GEMM_DGELU)), "mh_gemm_bf16: GELU epilogues need bf16 output");
+    MH_CHECK_ARG(!(flags & MH_GEMM_OUT_F32) || !(flags & (MH_GEMM_GELU | MH_GEMM_DGELU | MH_GEMM_MULAUX)), "mh_gemm_bf16: GELU / aux epilogues need bf16 output");
     MH_CHECK_ARG(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 == 0, "mh_gemm_bf16: bases must be 16-B aligned");
     if (layout == 2) {
         MH_CHECK_ARG(M % 8 == 0 && N % 8 == 0, "mh_gemm_bf16: TN needs M, N multiples of 8 (%d, %d)", M, N);
@@ -329,7 +329,9 @@ extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, cons
     }
     MH_CHECK_ARG(!(flags & MH_GEMM_BIAS) || bias, "mh_gemm_bf16: bias flag without pointer");
     MH_CHECK_ARG(!(flags & MH_GEMM_RESIDUAL) || (res && ldr % 4 == 0), "mh_gemm_bf16: residual needs pointer, ldr%%4==0");
-    MH_CHECK_ARG(!(flags & MH_GEMM_DGELU) || (aux_in && ldaux % 8 == 0), "mh_gemm_bf16: dgelu needs aux_in, ldaux %% 8 == 0");
+    MH_CHECK_ARG(!(flags & (MH_GEMM_DGELU | MH_GEMM_MULAUX)) || (aux_in && ldaux % 8 == 0), "mh_gemm_bf16: dgelu / mulaux need aux_in, ldaux %% 8 == 0");
+    MH_CHECK_ARG(!(flags & MH_GEMM_AUX_DGELU) || ((flags & MH_GEMM_GELU) && aux_out), "mh_gemm_bf16: aux_dgelu needs the GELU epilogue and aux_out");
+    MH_CHECK_ARG(!((flags & MH_GEMM_DGELU) && (flags & MH_GEMM_MULAUX)), "mh_gemm_bf16: dgelu and mulaux exclude each other");
     MH_CHECK_ARG(!(flags & MH_GEMM_GELU) || !aux_out || ldaux % 8 == 0, "mh_gemm_bf16: ldaux %% 8");
     MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || (flags & MH_GEMM_OUT_F32), "mh_gemm_bf16: atomic needs f32 output");
     MH_CHECK_ARG(!(flags & MH_GEMM_COLSUM) || (colsum && !(flags & MH_GEMM_OUT_F32)), "mh_gemm_bf16: colsum needs a pointer and bf16 output");

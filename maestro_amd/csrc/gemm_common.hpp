@@ -70,7 +70,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                 b_hi = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
             }
             u32x4 aux_pre[4];
-            if (p.flags & MH_GEMM_DGELU) {
+            if (p.flags & (MH_GEMM_DGELU | MH_GEMM_MULAUX)) {
 #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {
                     const int m = m_base + 32 * pass_m + pass * 8 + (l >> 3);
@@ -86,11 +86,24 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                 if (m < p.M && n < p.N) {
                     lo += b_lo; hi += b_hi;
                     if (p.flags & MH_GEMM_GELU) {
+                        f32x4 c_lo, d_lo, c_hi, d_hi;      // CDF and PDF of the pre-activation (one exp2 + one rcp per element)
+                        gelu_cdf_pdf4(lo, c_lo, d_lo);
+                        gelu_cdf_pdf4(hi, c_hi, d_hi);
                         if (p.aux_out) {
-                            u32x4 pk = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+                            f32x4 a_lo = lo, a_hi = hi;     // saved for the backward: the pre-activation, or GELU' = CDF + x PDF
+                            if (p.flags & MH_GEMM_AUX_DGELU) { a_lo = lo * d_lo + c_lo; a_hi = hi * d_hi + c_hi; }
+                            u32x4 pk = {pack_bf2(a_lo[0], a_lo[1]), pack_bf2(a_lo[2], a_lo[3]), pack_bf2(a_hi[0], a_hi[1]),
+                                        pack_bf2(a_hi[2], a_hi[3])};
                             *reinterpret_cast<u32x4*>(p.aux_out + (size_t)m * p.ldaux + n) = pk;
                         }
-                        lo = gelu_erf4(lo); hi = gelu_erf4(hi);
+                        lo *= c_lo; hi *= c_hi;
+                    }
+                    if (p.flags & MH_GEMM_MULAUX) {
+                        const u32x4 pk = aux_pre[pass];
+                        lo *= (f32x4){__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
+                                      __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+                        hi *= (f32x4){__uint_as_float(pk[2] << 16), __uint_as_float(pk[2] & 0xffff0000u),
+                                      __uint_as_float(pk[3] << 16), __uint_as_float(pk[3] & 0xffff0000u)};
                     }
                     if (p.flags & MH_GEMM_DGELU) {
                         const u32x4 pk = aux_pre[pass];

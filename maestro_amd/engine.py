@@ -181,8 +181,9 @@ class Stack:
                      hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=proj.bias, res=x_in, ldr=dim)
             ln2, fc1, fc2 = ff.net[0], ff.net[1], ff.net[4]
             hip.layernorm_fwd(x_mid, M, 0, ln2.weight, ln2.bias, s["h2"], M, 0, s["mean2"], s["rstd2"], 1, M, dim)
-            hip.gemm(hip.GEMM_NT, M, mlp, dim, s["h2"], dim, ps.h(fc1.weight), dim, s["act"], mlp, hip.BIAS | hip.GELU,
-                     bias=fc1.bias, aux_out=s["hpre"], ldaux=mlp)
+            # s["hpre"] receives GELU'(pre-activation): the forward epilogue has the CDF / PDF at hand, the backward multiplies
+            hip.gemm(hip.GEMM_NT, M, mlp, dim, s["h2"], dim, ps.h(fc1.weight), dim, s["act"], mlp,
+                     hip.BIAS | hip.GELU | hip.AUX_DGELU, bias=fc1.bias, aux_out=s["hpre"], ldaux=mlp)
             hip.gemm(hip.GEMM_NT, M, dim, mlp, s["act"], mlp, ps.h(fc2.weight), mlp, x_out, dim,
                      hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=fc2.bias, res=x_mid, ldr=dim)
 
@@ -228,7 +229,7 @@ class Stack:
             nxt = self.dxa if mid is not self.dxa else self.dxb
             nxt16 = self.saved[l - 1]["gy16"] if l > 0 else self.dx0_16
             # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-            hip.gemm(hip.GEMM_NN, M, mlp, dim, cur16, dim, ps.h(fc2.weight), mlp, dh, mlp, hip.DGELU | hip.COLSUM,
+            hip.gemm(hip.GEMM_NN, M, mlp, dim, cur16, dim, ps.h(fc2.weight), mlp, dh, mlp, hip.MULAUX | hip.COLSUM,
                      aux_in=s["hpre"], ldaux=mlp, colsum=self.cs_ws)
             hip.colsum(self.cs_ws, ps.g(fc1.bias), self.cs_rows, mlp, mlp)   # fc1 bias gradient from the block partials
             if not defer:

@@ -18,5 +18,7 @@ for (M, N, K) in ((8192, 3072, 768), (32768, 3072, 512), (3200, 3072, 768)):
     r = {"NT plain": t(lambda: hip.gemm(0, M, N, K, A, K, Wt, K, C, N, hip.BIAS, bias=bias)),
          "NT gelu+aux": t(lambda: hip.gemm(0, M, N, K, A, K, Wt, K, C, N, hip.BIAS | hip.GELU, bias=bias, aux_out=aux, ldaux=N)),
          "NN plain": t(lambda: hip.gemm(1, M, N, K, A, K, Wn, N, C, N, 0)),
-         "NN dgelu": t(lambda: hip.gemm(1, M, N, K, A, K, Wn, N, C, N, hip.DGELU, aux_in=aux, ldaux=N))}
+         "NT gelu+daux": t(lambda: hip.gemm(0, M, N, K, A, K, Wt, K, C, N, hip.BIAS | hip.GELU | hip.AUX_DGELU, bias=bias, aux_out=aux, ldaux=N)),
+         "NN dgelu": t(lambda: hip.gemm(1, M, N, K, A, K, Wn, N, C, N, hip.DGELU, aux_in=aux, ldaux=N)),
+         "NN mulaux": t(lambda: hip.gemm(1, M, N, K, A, K, Wn, N, C, N, hip.MULAUX, aux_in=aux, ldaux=N))}
     print(f"({M},{N},{K}) " + " | ".join(f"{k} {v*1e3:6.1f}us {fl/v/1e9:5.0f}TF" for k, v in r.items()), flush=True)

@@ -89,6 +89,22 @@ def test_gemm_epilogues():
     x = aux.float().requires_grad_(True)
     torch.nn.functional.gelu(x).sum().backward()
     assert (C.float() - want * x.grad).abs().max() < 3e-2
+    # the pair the engine uses: the forward saves GELU'(pre-activation) (AUX_DGELU), the backward multiplies by it (MULAUX)
+    dsave = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    hip.gemm(0, M, N, K, A, K, B, K, C, N, hip.BIAS | hip.GELU | hip.AUX_DGELU, bias=bias, aux_out=dsave, ldaux=N)
+    torch.cuda.synchronize()
+    assert (C.float() - torch.nn.functional.gelu(pre)).abs().max() < 2e-2
+    xp = pre.clone().requires_grad_(True)
+    torch.nn.functional.gelu(xp).sum().backward()
+    assert (dsave.float() - xp.grad).abs().max() < 1e-2, "saved derivative differs from GELU'(x)"
+    hip.gemm(0, M, N, K, A, K, B, K, C, N, hip.MULAUX, aux_in=dsave, ldaux=N)
+    torch.cuda.synchronize()
+    prod = want * dsave.float()
+    assert ((C.float() - prod).abs().max() / prod.abs().max()).item() < 1e-2
+    with pytest.raises(hip.HipExtensionError):
+        hip.gemm(0, M, N, K, A, K, B, K, C, N, hip.AUX_DGELU, aux_out=dsave, ldaux=N)          # needs the GELU epilogue
+    with pytest.raises(hip.HipExtensionError):
+        hip.gemm(0, M, N, K, A, K, B, K, C, N, hip.MULAUX | hip.DGELU, aux_in=dsave, ldaux=N)   # exclusive
 
 
 def test_gemm_bad_arguments_fail_loudly():
