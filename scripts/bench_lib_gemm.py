@@ -20,3 +20,14 @@ for (M, N, K) in ((768, 3072, 8192), (3072, 768, 8192), (512, 3072, 32768)):
     dY = torch.randn(K, M, device=dev).bfloat16(); X = torch.randn(K, N, device=dev).bfloat16()
     tn = t(lambda: torch.matmul(dY.t(), X))
     print(f"TN ({M},{N},{K}) lib {tn*1e3:6.1f}us {2.0*M*N*K/tn/1e9:5.0f}TF", flush=True)
+# fp8 (OCP e4m3, per-tensor scales) through the vendor library: what the C5 "fp8 path" could buy on the same shapes
+try:
+    one = torch.ones((), device=dev)
+    for (M, N, K) in ((8192, 3072, 768), (8192, 768, 3072), (8192, 2304, 768), (32768, 3072, 512), (32768, 512, 3072)):
+        A8 = torch.randn(M, K, device=dev).to(torch.float8_e4m3fn); W8 = torch.randn(N, K, device=dev).to(torch.float8_e4m3fn)
+        f8 = t(lambda: torch._scaled_mm(A8, W8.t(), scale_a=one, scale_b=one, out_dtype=torch.bfloat16))
+        Ab = torch.randn(M, K, device=dev).bfloat16(); Wb = torch.randn(N, K, device=dev).bfloat16()
+        b16 = t(lambda: torch.matmul(Ab, Wb.t()))
+        print(f"({M},{N},{K}) lib fp8 NT {f8*1e3:6.1f}us {2.0*M*N*K/f8/1e9:5.0f}TF | lib bf16 NT {b16*1e3:6.1f}us {2.0*M*N*K/b16/1e9:5.0f}TF", flush=True)
+except Exception as exc:  # noqa: BLE001
+    print("fp8 library GEMM not available here:", type(exc).__name__, str(exc)[:200])
