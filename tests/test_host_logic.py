@@ -205,3 +205,24 @@ def test_head_state_dict_keys_match_oracle():
         assert set(ours) == set(ref), (name, set(ours) ^ set(ref))
         assert all(ours[k].shape == ref[k].shape for k in ref), name
         assert any(k.startswith("heads.") for k in ref)
+
+
+def test_adamw_bias_corrections_are_float32_like_the_kernel_host_side():
+    """``mh_adamw`` computes 1 - b1^t and sqrt(1 - b2^t) in float32 (powf / sqrtf); the device-scalar variant gets the same
+    bits from ``hip.adamw_bias_corrections`` (no GPU or library needed: libm only)."""
+    import numpy as np
+
+    from maestro_amd import hip
+    for t in (1, 2, 7, 100, 5000):
+        bc1, bc2 = hip.adamw_bias_corrections(0.9, 0.99, t)
+        assert bc1 == float(np.float32(1.0) - np.float32(0.9) ** np.float32(t)) or abs(bc1 - (1 - 0.9 ** t)) < 1e-6
+        assert abs(bc2 - (1 - 0.99 ** t) ** 0.5) < 1e-6        # float32 arithmetic on purpose (0.99 is not exact in float32)
+        assert np.float32(bc1) == bc1 and np.float32(bc2) == bc2      # exactly representable: they cross the ABI as float
+
+
+def test_lr_rule_counts_micro_batches_like_the_reference():
+    """model.py:120-128: lr = base_lr * sqrt(batch * accumulate * nodes * devices / 3)."""
+    from maestro_amd.train.optim import scaled_lr
+    assert scaled_lr(3e-5, 32, 1, 1, 1) == pytest.approx(3e-5 * (32 / 3) ** 0.5)
+    assert scaled_lr(3e-5, 32, 4, 1, 8) == pytest.approx(3e-5 * (32 * 4 * 8 / 3) ** 0.5)
+    assert scaled_lr(3e-5, 32, 2, 1, 1) == pytest.approx(scaled_lr(3e-5, 64, 1, 1, 1))
