@@ -99,6 +99,20 @@ int mh_layernorm_bwd(const void* dy, int dy_L, int dy_off, int dy_is_f32, const 
                      void* dx_bf16, float* dgamma, float* dbeta, float* dcol, float* workspace, int B, int n, int dim,
                      void* stream);
 long mh_layernorm_bwd_workspace(int rows, int dim);
+/* The same backward with the parameter-gradient reduce left to the caller: only writes the per-block partial rows
+ * [mh_layernorm_bwd_workspace / (3 dim)][3 dim] = (dgamma | dbeta | colsum(dx)) into `workspace`; a later
+ * mh_colsum_batched over many such workspaces replaces one small reduce launch per LayerNorm. */
+int mh_layernorm_bwd_partial(const void* dy, int dy_L, int dy_off, int dy_is_f32, const float* x, int x_L, int x_off,
+                             const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
+                             void* dx_bf16, float* workspace, int B, int n, int dim, void* stream);
+/* Batched column sums: for every job, dst[c] += sum over r < rows of src[r * ld + c] (c < cols), all jobs in ONE launch
+ * (fp32 atomics: dst must hold the value to add to).  jobs is a device array; max_rows / max_cols bound the grid. */
+typedef struct {
+    const float* src;
+    float* dst;
+    int rows, cols, ld, reserved;
+} MhColsumJob;
+int mh_colsum_batched(const MhColsumJob* jobs_device, int n_jobs, int max_rows, int max_cols, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- attention
  * Fused softmax(Q K^T * scale) V, no mask, no dropout (vit_pytorch Attention.forward; call sites mae.py:135-174).

@@ -198,6 +198,19 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     else if (dcol) atomicAdd(dcol + (c - 2 * dim), s);
 }
 
+// One launch for many small column sums (LayerNorm partial rows, bias block sums): grid (column blocks, row chunks, jobs).
+constexpr int CB_ROWS = 16;
+__global__ __launch_bounds__(256) void colsum_batched_kernel(const MhColsumJob* __restrict__ jobs) {
+    const MhColsumJob j = jobs[blockIdx.z];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * CB_ROWS;
+    if (c >= j.cols || r0 >= j.rows) return;
+    const int r1 = min(j.rows, r0 + CB_ROWS);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += j.src[(size_t)r * j.ld + c];
+    atomicAdd(j.dst + c, s);
+}
+
 }  // namespace
 
 static int ln_nv(int dim) { const int v = (dim / 4 + 63) / 64; return v <= 4 ? v : 8; }
@@ -224,6 +237,27 @@ extern "C" long mh_layernorm_bwd_workspace(int rows, int dim) {
     return (long)ceil_div(rows, 4 * ROWS_PER_WAVE) * 3 * dim;
 }
 
+static int layernorm_bwd_impl(const void* dy, int dy_L, int dy_off, int dy_is_f32, const float* x, int x_L, int x_off,
+                              const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
+                              void* dx_bf16, float* dgamma, float* dbeta, float* dcol, float* workspace, bool partial_only,
+                              int B, int n, int dim, void* stream) {
+    const int rows = B * n, nblk = ceil_div(rows, 4 * ROWS_PER_WAVE);
+    const size_t lds = (size_t)4 * 3 * dim * sizeof(float);
+    dim3 grid(nblk), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (dgamma || partial_only) ? workspace : nullptr;
+#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, lds, s, dy, RowMap{dy_L, dy_off}, dy_is_f32, x, \
+                                      RowMap{x_L, x_off}, gamma, mean, rstd, dres, dx, (bf16_t*)dx_bf16, part, B, n, dim)
+    switch (ln_nv(dim)) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break;
+                          case 4: LN_BWD(4); break; default: LN_BWD(8); }
+#undef LN_BWD
+    if (dgamma && !partial_only)
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(3 * dim, 256), ceil_div(nblk, RED_ROWS)), dim3(256), 0, s,
+                           workspace, nblk, dim, dgamma, dbeta, dcol);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int mh_layernorm_bwd(const void* dy, int dy_L, int dy_off, int dy_is_f32, const float* x, int x_L, int x_off,
                                 const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
                                 void* dx_bf16, float* dgamma, float* dbeta, float* dcol, float* workspace, int B, int n,
@@ -234,19 +268,24 @@ extern "C" int mh_layernorm_bwd(const void* dy, int dy_L, int dy_off, int dy_is_
     MH_CHECK_ARG(!dcol || dgamma, "mh_layernorm_bwd: dcol needs dgamma/dbeta");
     MH_CHECK_ARG(dim % 4 == 0 && dim >= 4 && dim <= 2048, "mh_layernorm_bwd: dim %d unsupported", dim);
     MH_CHECK_ARG(B > 0 && n > 0 && x_off + n <= x_L && dy_off + n <= dy_L, "mh_layernorm_bwd: bad row map");
-    const int rows = B * n, nblk = ceil_div(rows, 4 * ROWS_PER_WAVE);
-    const size_t lds = (size_t)4 * 3 * dim * sizeof(float);
-    dim3 grid(nblk), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    float* part = dgamma ? workspace : nullptr;
-#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, lds, s, dy, RowMap{dy_L, dy_off}, dy_is_f32, x, \
-                                      RowMap{x_L, x_off}, gamma, mean, rstd, dres, dx, (bf16_t*)dx_bf16, part, B, n, dim)
-    switch (ln_nv(dim)) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break;
-                          case 4: LN_BWD(4); break; default: LN_BWD(8); }
-#undef LN_BWD
-    if (dgamma)
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(3 * dim, 256), ceil_div(nblk, RED_ROWS)), dim3(256), 0, s,
-                           workspace, nblk, dim, dgamma, dbeta, dcol);
+    return layernorm_bwd_impl(dy, dy_L, dy_off, dy_is_f32, x, x_L, x_off, gamma, mean, rstd, dres, dx, dx_bf16, dgamma, dbeta, dcol,
+                              workspace, false, B, n, dim, stream);
+}
+
+extern "C" int mh_layernorm_bwd_partial(const void* dy, int dy_L, int dy_off, int dy_is_f32, const float* x, int x_L, int x_off,
+                                        const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
+                                        void* dx_bf16, float* workspace, int B, int n, int dim, void* stream) {
+    MH_CHECK_ARG(dy && x && gamma && mean && rstd && dx && workspace, "mh_layernorm_bwd_partial: null pointer");
+    MH_CHECK_ARG(dim % 4 == 0 && dim >= 4 && dim <= 2048, "mh_layernorm_bwd_partial: dim %d unsupported", dim);
+    MH_CHECK_ARG(B > 0 && n > 0 && x_off + n <= x_L && dy_off + n <= dy_L, "mh_layernorm_bwd_partial: bad row map");
+    return layernorm_bwd_impl(dy, dy_L, dy_off, dy_is_f32, x, x_L, x_off, gamma, mean, rstd, dres, dx, dx_bf16, nullptr, nullptr,
+                              nullptr, workspace, true, B, n, dim, stream);
+}
+
+extern "C" int mh_colsum_batched(const MhColsumJob* jobs_device, int n_jobs, int max_rows, int max_cols, void* stream) {
+    MH_CHECK_ARG(jobs_device && n_jobs > 0 && n_jobs < 65536 && max_rows > 0 && max_cols > 0, "mh_colsum_batched: bad arguments");
+    hipLaunchKernelGGL(colsum_batched_kernel, dim3(ceil_div(max_cols, 256), ceil_div(max_rows, CB_ROWS), n_jobs), dim3(256), 0,
+                       (hipStream_t)stream, jobs_device);
     MH_LAUNCH_CHECK();
     return 0;
 }

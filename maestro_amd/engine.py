@@ -147,6 +147,11 @@ class Stack:
         self.ln_ws = e(max(1, hip.layernorm_bwd_workspace(M, dim)))  # private: stacks of different groups run concurrently
         self.cs_rows = (M + 63) // 64
         self.cs_ws = e(self.cs_rows, mlp)     # per-64-row-block column sums of d fc1-out (GEMM epilogue side output)
+        # deferred reductions: per-layer copies of the two workspaces above, so that the parameter-gradient reduces of a
+        # whole backward segment (2 LayerNorms + the fc1 bias per layer) run as ONE batched column-sum launch
+        self.ln_rows = hip.layernorm_bwd_workspace(M, dim) // (3 * dim)
+        for s in self.saved:
+            s.update(ws1=e(self.ln_rows, 3 * dim), ws2=e(self.ln_rows, 3 * dim), cs=e(self.cs_rows, mlp))
 
     @property
     def x0(self):
@@ -186,6 +191,23 @@ class Stack:
                      hip.BIAS | hip.GELU | hip.AUX_DGELU, bias=fc1.bias, aux_out=s["hpre"], ldaux=mlp)
             hip.gemm(hip.GEMM_NT, M, dim, mlp, s["act"], mlp, ps.h(fc2.weight), mlp, x_out, dim,
                      hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=fc2.bias, res=x_mid, ldr=dim)
+
+    def reduce_jobs(self, lo: int = 0, hi: int | None = None) -> list:
+        """``hip.ColsumBatch`` jobs of layers ``lo .. hi-1`` after a ``backward(defer=True)``: the LayerNorm partial rows
+        (dgamma | dbeta | colsum dx = the bias gradient of the Linear that fed the residual) and the fc1 bias block sums."""
+        ps, dim, mlp, jobs = self.eng.store, self.dim, self.mlp, []
+        for l in range(lo, self.depth if hi is None else hi):
+            attn, ff = self.t.layers[l]
+            s, ln2, fc1, proj = self.saved[l], ff.net[0], ff.net[1], attn.to_out[0]
+            jobs.append((s["cs"], ps.g(fc1.bias), self.cs_rows, mlp, mlp))
+            for ws, norm, bias in ((s["ws2"], ln2, ps.g(proj.bias)),
+                                   (s["ws1"], attn.norm, ps.g(self.t.layers[l - 1][1].net[4].bias) if l > 0 else None)):
+                flat = ws.view(-1)
+                jobs.append((flat, ps.g(norm.weight), self.ln_rows, dim, 3 * dim))
+                jobs.append((flat[dim:], ps.g(norm.bias), self.ln_rows, dim, 3 * dim))
+                if bias is not None:
+                    jobs.append((flat[2 * dim:], bias, self.ln_rows, dim, 3 * dim))
+        return jobs
 
     def wgrad_problems(self, lo: int = 0, hi: int | None = None) -> list:
         """The four weight-gradient GEMMs dW[out, in] = dY[M, out]^T X[M, in] of layers ``lo .. hi-1`` as
@@ -230,14 +252,18 @@ class Stack:
             nxt16 = self.saved[l - 1]["gy16"] if l > 0 else self.dx0_16
             # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
             hip.gemm(hip.GEMM_NN, M, mlp, dim, cur16, dim, ps.h(fc2.weight), mlp, dh, mlp, hip.MULAUX | hip.COLSUM,
-                     aux_in=s["hpre"], ldaux=mlp, colsum=self.cs_ws)
-            hip.colsum(self.cs_ws, ps.g(fc1.bias), self.cs_rows, mlp, mlp)   # fc1 bias gradient from the block partials
+                     aux_in=s["hpre"], ldaux=mlp, colsum=s["cs"] if defer else self.cs_ws)
             if not defer:
+                hip.colsum(self.cs_ws, ps.g(fc1.bias), self.cs_rows, mlp, mlp)   # fc1 bias gradient from the block partials
                 hip.gemm(hip.GEMM_TN, dim, mlp, M, cur16, dim, s["act"], mlp, ps.g(fc2.weight), mlp, AT)
                 hip.gemm(hip.GEMM_TN, mlp, dim, M, dh, mlp, s["h2"], dim, ps.g(fc1.weight), dim, AT)
             hip.gemm(hip.GEMM_NN, M, dim, mlp, dh, mlp, ps.h(fc1.weight), dim, self.dh2, dim)
-            hip.layernorm_bwd(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16,
-                              ps.g(ln2.weight), ps.g(ln2.bias), ps.g(proj.bias), self.ln_ws, 1, M, dim)
+            if defer:   # parameter gradients: partial rows now, one batched reduce per segment (reduce_jobs)
+                hip.layernorm_bwd_partial(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16, s["ws2"],
+                                          1, M, dim)
+            else:
+                hip.layernorm_bwd(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16,
+                                  ps.g(ln2.weight), ps.g(ln2.bias), ps.g(proj.bias), self.ln_ws, 1, M, dim)
             # ---- attention: x_mid = x_in + proj(attn(qkv(LN1(x_in))))
             hip.gemm(hip.GEMM_NN, M, inner, dim, mid16, dim, ps.h(proj.weight), inner, self.do, inner)
             if not defer:
@@ -247,8 +273,12 @@ class Stack:
                 hip.gemm(hip.GEMM_TN, 3 * inner, dim, M, dqkv, 3 * inner, s["h1"], dim, ps.g(attn.to_qkv.weight), dim, AT)
             hip.gemm(hip.GEMM_NN, M, dim, 3 * inner, dqkv, 3 * inner, ps.h(attn.to_qkv.weight), dim, self.dh2, dim)
             prev_fc2_bias = ps.g(self.t.layers[l - 1][1].net[4].bias) if l > 0 else None  # = colsum(dx_out of layer l-1)
-            hip.layernorm_bwd(self.dh2, M, 0, x_in, M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid, nxt, nxt16,
-                              ps.g(attn.norm.weight), ps.g(attn.norm.bias), prev_fc2_bias, self.ln_ws, 1, M, dim)
+            if defer:
+                hip.layernorm_bwd_partial(self.dh2, M, 0, x_in, M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid, nxt, nxt16,
+                                          s["ws1"], 1, M, dim)
+            else:
+                hip.layernorm_bwd(self.dh2, M, 0, x_in, M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid, nxt, nxt16,
+                                  ps.g(attn.norm.weight), ps.g(attn.norm.bias), prev_fc2_bias, self.ln_ws, 1, M, dim)
             cur, cur16 = nxt, nxt16
             if ready:
                 eng._grads_ready(self.t.layers[l])
@@ -814,8 +844,10 @@ class MAEEngine(EngineBase):
         table = self._wgrad_tables.get(key)
         if table is None:
             probs = [p for st, lo, hi in items for p in st.wgrad_problems(lo, hi)]
-            table = self._wgrad_tables[key] = hip.GroupedTN(probs, self.device)
-        table.launch()
+            jobs = [j for st, lo, hi in items for j in st.reduce_jobs(lo, hi)]
+            table = self._wgrad_tables[key] = (hip.GroupedTN(probs, self.device), hip.ColsumBatch(jobs, self.device))
+        table[1].launch()   # LayerNorm / bias parameter gradients of the same layers: one batched column-sum launch
+        table[0].launch()
 
     def _enc_cuts(self) -> list:
         # encoder side: with a gradient hook (data parallel) cut it into layer ranges so the all-reduce of the finished

@@ -413,6 +413,8 @@ class SupervisedEngine(EngineBase):
             stacks = list(self.enc.values()) + ([self.joint] if self.joint is not None else [])
             if not hasattr(self, "_wgrad_table"):
                 self._wgrad_table = hip.GroupedTN([p for st in stacks for p in st.wgrad_problems()], self.device)
+                self._reduce_table = hip.ColsumBatch([j for st in stacks for j in st.reduce_jobs()], self.device)
+            self._reduce_table.launch()   # deferred LayerNorm / bias parameter gradients of the stacks (one launch)
             self._wgrad_table.launch()
         for name in m.patch_embed:
             self._grads_ready(m.patch_embed[name])

@@ -344,3 +344,40 @@ def test_colsum_cast_pack_adamw(dev):
         hip.adamw(p, g, m, v, pb, n, 1e-2, 0.9, 0.99, 1e-8, 0.01, step)
     assert (p - p_ref.detach()).abs().max() < 1e-5
     assert torch.equal(pb, p.bfloat16())
+
+
+def test_layernorm_partial_plus_batched_colsum_equals_fused_reduce():
+    """``mh_layernorm_bwd_partial`` + ``mh_colsum_batched`` (the per-segment batched form the engines use) give the same dx
+    and the same dgamma / dbeta / dcol as ``mh_layernorm_bwd`` with its own reduce; a second job type (plain matrix) too."""
+    from maestro_amd import hip
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    rows, dim = 403, 192                                      # ragged: not a multiple of the 16 rows per block
+    x = torch.randn(rows, dim, generator=g).to(dev)
+    dy = torch.randn(rows, dim, generator=g).to(dev).bfloat16()
+    dres = torch.randn(rows, dim, generator=g).to(dev)
+    gamma = torch.randn(dim, generator=g).to(dev)
+    mean, rstd = x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    n_ws = hip.layernorm_bwd_workspace(rows, dim)
+    ws_a, ws_b = torch.empty(n_ws, device=dev), torch.full((n_ws,), float("nan"), device=dev)
+    dx_a, dx_b = torch.empty_like(x), torch.empty_like(x)
+    dg_a, db_a, dc_a = (torch.zeros(dim, device=dev) for _ in range(3))
+    hip.layernorm_bwd(dy, rows, 0, x, rows, 0, gamma, mean, rstd, dres, dx_a, None, dg_a, db_a, dc_a, ws_a, 1, rows, dim)
+    hip.layernorm_bwd_partial(dy, rows, 0, x, rows, 0, gamma, mean, rstd, dres, dx_b, None, ws_b, 1, rows, dim)
+    nblk = n_ws // (3 * dim)
+    dg_b, db_b, dc_b = (torch.full((dim,), 0.5, device=dev) for _ in range(3))        # += semantics: starts at 0.5
+    mat = torch.randn(37, 100, generator=g).to(dev)
+    msum = torch.zeros(64, device=dev)
+    flat = ws_b.view(-1)
+    batch = hip.ColsumBatch([(flat, dg_b, nblk, dim, 3 * dim), (flat[dim:], db_b, nblk, dim, 3 * dim),
+                             (flat[2 * dim:], dc_b, nblk, dim, 3 * dim), (mat, msum, 37, 64, 100)], dev)
+    batch.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(dx_a, dx_b)
+    for a, b in ((dg_a, dg_b), (db_a, db_b), (dc_a, dc_b)):
+        assert torch.allclose(a + 0.5, b, rtol=1e-5, atol=1e-4), (a - b + 0.5).abs().max()
+    assert torch.allclose(msum, mat[:, :64].sum(0), rtol=1e-5, atol=1e-5)
+    with pytest.raises(hip.HipExtensionError):
+        hip.ColsumBatch([(mat, msum, 37, 128, 100)], dev)                              # cols > ld
