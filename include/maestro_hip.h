@@ -106,13 +106,16 @@ int mh_layernorm_bwd_partial(const void* dy, int dy_L, int dy_off, int dy_is_f32
                              const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
                              void* dx_bf16, float* workspace, int B, int n, int dim, void* stream);
 /* Batched column sums: for every job, dst[c] += sum over r < rows of src[r * ld + c] (c < cols), all jobs in ONE launch
- * (fp32 atomics: dst must hold the value to add to).  jobs is a device array; max_rows / max_cols bound the grid. */
+ * (fp32 atomics: dst must hold the value to add to).  jobs and blocks are device arrays; blocks lists the work items of
+ * the launch, one per workgroup: job << 48 | column block (256 columns) << 32 | row chunk (MH_COLSUM_ROWS rows), so that
+ * jobs of very different shapes share a dense grid. */
+#define MH_COLSUM_ROWS 16
 typedef struct {
     const float* src;
     float* dst;
     int rows, cols, ld, reserved;
 } MhColsumJob;
-int mh_colsum_batched(const MhColsumJob* jobs_device, int n_jobs, int max_rows, int max_cols, void* stream);
+int mh_colsum_batched(const MhColsumJob* jobs_device, int n_jobs, const uint64_t* blocks_device, int n_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- attention
  * Fused softmax(Q K^T * scale) V, no mask, no dropout (vit_pytorch Attention.forward; call sites mae.py:135-174).

@@ -198,14 +198,18 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     else if (dcol) atomicAdd(dcol + (c - 2 * dim), s);
 }
 
-// One launch for many small column sums (LayerNorm partial rows, bias block sums): grid (column blocks, row chunks, jobs).
-constexpr int CB_ROWS = 16;
-__global__ __launch_bounds__(256) void colsum_batched_kernel(const MhColsumJob* __restrict__ jobs) {
-    const MhColsumJob j = jobs[blockIdx.z];
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    const int r0 = blockIdx.y * CB_ROWS;
+// One launch for many small column sums (LayerNorm partial rows, bias block sums): workgroup b runs the host-listed work item
+// blocks[b] = (job, column block, row chunk), so jobs of very different shapes share a dense grid.
+__global__ __launch_bounds__(256) void colsum_batched_kernel(const MhColsumJob* __restrict__ jobs, int n_jobs,
+                                                             const uint64_t* __restrict__ blocks) {
+    const uint64_t e = blocks[blockIdx.x];
+    const int ji = (int)(e >> 48);
+    if (ji >= n_jobs) return;
+    const MhColsumJob j = jobs[ji];
+    const int c = (int)((e >> 32) & 0xFFFF) * 256 + threadIdx.x;
+    const int r0 = (int)(e & 0xFFFFFFFFu) * MH_COLSUM_ROWS;
     if (c >= j.cols || r0 >= j.rows) return;
-    const int r1 = min(j.rows, r0 + CB_ROWS);
+    const int r1 = min(j.rows, r0 + MH_COLSUM_ROWS);
     float s = 0.f;
     for (int r = r0; r < r1; ++r) s += j.src[(size_t)r * j.ld + c];
     atomicAdd(j.dst + c, s);
@@ -282,10 +286,10 @@ extern "C" int mh_layernorm_bwd_partial(const void* dy, int dy_L, int dy_off, in
                               nullptr, workspace, true, B, n, dim, stream);
 }
 
-extern "C" int mh_colsum_batched(const MhColsumJob* jobs_device, int n_jobs, int max_rows, int max_cols, void* stream) {
-    MH_CHECK_ARG(jobs_device && n_jobs > 0 && n_jobs < 65536 && max_rows > 0 && max_cols > 0, "mh_colsum_batched: bad arguments");
-    hipLaunchKernelGGL(colsum_batched_kernel, dim3(ceil_div(max_cols, 256), ceil_div(max_rows, CB_ROWS), n_jobs), dim3(256), 0,
-                       (hipStream_t)stream, jobs_device);
+extern "C" int mh_colsum_batched(const MhColsumJob* jobs_device, int n_jobs, const uint64_t* blocks_device, int n_blocks,
+                                 void* stream) {
+    MH_CHECK_ARG(jobs_device && blocks_device && n_jobs > 0 && n_jobs < 65536 && n_blocks > 0, "mh_colsum_batched: bad arguments");
+    hipLaunchKernelGGL(colsum_batched_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, n_jobs, blocks_device);
     MH_LAUNCH_CHECK();
     return 0;
 }

@@ -186,6 +186,9 @@ def layernorm_bwd_partial(dy, dy_L, dy_off, x, x_L, x_off, gamma, mean, rstd, dr
          gamma, mean, rstd, dres, dx, dx_bf16, workspace, _I(B), _I(n), _I(dim))
 
 
+COLSUM_ROWS = 16   # MH_COLSUM_ROWS in include/maestro_hip.h
+
+
 class _MhColsumJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
                 ("ld", ctypes.c_int), ("reserved", ctypes.c_int)]
@@ -207,10 +210,17 @@ class ColsumBatch:
             arr[i] = _MhColsumJob(src.data_ptr(), dst.data_ptr(), rows, cols, ld, 0)
         self.keep = [t for job in jobs for t in job[:2]]     # the descriptors hold raw pointers
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
-        self.n, self.max_rows, self.max_cols = len(jobs), max(j[2] for j in jobs), max(j[3] for j in jobs)
+        blocks = []                                          # one work item per workgroup: job << 48 | column block << 32 | row chunk
+        for i, (_, _, rows, cols, _) in enumerate(jobs):
+            if cols > 65535 * 256 or len(jobs) > 32767:
+                raise HipExtensionError("ColsumBatch: too many jobs / columns for the work-item encoding")
+            for cb in range(-(-cols // 256)):
+                blocks += [(i << 48) | (cb << 32) | rc for rc in range(-(-rows // COLSUM_ROWS))]
+        self.blocks = torch.tensor(blocks, dtype=torch.int64).to(device)
+        self.n, self.n_blocks = len(jobs), len(blocks)
 
     def launch(self) -> None:
-        call("mh_colsum_batched", self.table, _I(self.n), _I(self.max_rows), _I(self.max_cols))
+        call("mh_colsum_batched", self.table, _I(self.n), self.blocks, _I(self.n_blocks))
 
 
 def attn_fwd(qkv, out, lse, B, N, H, D, scale):
@@ -478,6 +488,9 @@ def layernorm_bwd_partial(dy, dy_L, dy_off, x, x_L, x_off, gamma, mean, rstd, dr
          gamma, mean, rstd, dres, dx, dx_bf16, workspace, _I(B), _I(n), _I(dim))
 
 
+COLSUM_ROWS = 16   # MH_COLSUM_ROWS in include/maestro_hip.h
+
+
 class _MhColsumJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
                 ("ld", ctypes.c_int), ("reserved", ctypes.c_int)]
@@ -499,10 +512,17 @@ class ColsumBatch:
             arr[i] = _MhColsumJob(src.data_ptr(), dst.data_ptr(), rows, cols, ld, 0)
         self.keep = [t for job in jobs for t in job[:2]]     # the descriptors hold raw pointers
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
-        self.n, self.max_rows, self.max_cols = len(jobs), max(j[2] for j in jobs), max(j[3] for j in jobs)
+        blocks = []                                          # one work item per workgroup: job << 48 | column block << 32 | row chunk
+        for i, (_, _, rows, cols, _) in enumerate(jobs):
+            if cols > 65535 * 256 or len(jobs) > 32767:
+                raise HipExtensionError("ColsumBatch: too many jobs / columns for the work-item encoding")
+            for cb in range(-(-cols // 256)):
+                blocks += [(i << 48) | (cb << 32) | rc for rc in range(-(-rows // COLSUM_ROWS))]
+        self.blocks = torch.tensor(blocks, dtype=torch.int64).to(device)
+        self.n, self.n_blocks = len(jobs), len(blocks)
 
     def launch(self) -> None:
-        call("mh_colsum_batched", self.table, _I(self.n), _I(self.max_rows), _I(self.max_cols))
+        call("mh_colsum_batched", self.table, _I(self.n), self.blocks, _I(self.n_blocks))
 
 
 def attn_fwd(qkv, out, lse, B, N, H, D, scale):  # noqa: F811
