@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
     f32x4 acc = {0, 0, 0, 0};
     if (c < N) {
+#pragma unroll 8   // independent row loads: keep eight in flight per lane (the loop was latency-bound at ~1 TB/s)
         for (int r = r0 + w; r < r1; r += 4) {
             if (is_f32) {
                 acc += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + (size_t)r * ld + c);
@@ -167,10 +168,11 @@ extern "C" int mh_masked_loss(const float* rec, const float* target, const uint8
 
 extern "C" int mh_colsum(const void* x, int x_is_f32, float* out, int M, int N, int ld, void* stream) {
     MH_CHECK_ARG(x && out && N % 4 == 0 && ld % 4 == 0, "mh_colsum: bad arguments");
-    // enough blocks to fill 256 CUs (>= ~1024) while keeping a few hundred atomics per column at most
+    // 128-256 rows per block: fewer rows mean more workgroups but also more same-address atomics per column (32-row blocks
+    // took 57 us for 32768 x 768 bf16, 256-row blocks 32 us; 12800 x 200: 41 -> 15 us), more rows starve the CUs
     const int col_blocks = ceil_div(N, 256);
-    int rows_per_block = 512;
-    while (rows_per_block > 32 && (long)col_blocks * ceil_div(M, rows_per_block) < 1024) rows_per_block >>= 1;
+    int rows_per_block = 256;
+    if ((long)col_blocks * ceil_div(M, rows_per_block) < 256) rows_per_block = 128;
     hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 256), ceil_div(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream, x,
                        x_is_f32, out, M, N, ld, rows_per_block);
     MH_LAUNCH_CHECK();
