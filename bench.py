@@ -106,12 +106,22 @@ def build_model(workload: str, phase: str = "pretrain"):
 
 
 def host_cores() -> int:
-    """Threads for the CPU leg: the affinity mask, capped at the 16-core share a 1-GPU box gets."""
+    """Threads for the CPU leg (every host core this process may run on, count stated in the line)."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, 16))
+    return max(1, n)
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline_worker(workload: str, seconds: float, phase: str = "pretrain") -> dict:
@@ -129,12 +139,12 @@ def cpu_baseline_worker(workload: str, seconds: float, phase: str = "pretrain") 
     model = om.build_oracle(ds, conf.MaskConfig(), model_size=w["size"], interpolate="nearest", fusion_mode="group",
                             inter_depth=3, model="mae", num_levels=1)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.99), weight_decay=0.01)
-    B = 2  # noqa: N806
+    B, WARM = 4, 2  # noqa: N806  (CPU batch 4-8, two warm-up steps, median of the timed ones)
     batch = synthetic_batch(ds.dataset, B, "cpu")
     batch.update(synthetic_targets(ds.dataset, B, "cpu"))
     times = []
     t_end = time.time() + seconds
-    for i in range(50):
+    for i in range(50 + WARM):
         t0 = time.time()
         if phase == "pretrain":
             loss, _, _ = om.oracle_step(model, batch, "l2_norm")
@@ -145,22 +155,23 @@ def cpu_baseline_worker(workload: str, seconds: float, phase: str = "pretrain") 
         loss.backward()
         opt.step()
         dt = time.time() - t0
-        if i > 0:
+        if i >= WARM:
             times.append(dt)
-        if time.time() > t_end and len(times) >= 1:
+        if time.time() > t_end and len(times) >= 5:    # >= 5 timed steps, bounded by the seconds budget
             break
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(B / med, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} timed steps (after 1 warm-up) of the same {workload} {phase} workload at B={B}, fp32, "
-                      f"torch CPU threads={cores}, forward+loss+backward+AdamW, median step {med:.2f} s"}
+    return {"value": round(B / med, 4), "unit": "tiles/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": f"{len(times)} timed steps (after {WARM} warm-ups) of the same {workload} {phase} workload at B={B}, fp32 "
+                      f"('highest' matmul precision), torch CPU threads={cores}, forward+loss+backward+AdamW, median step "
+                      f"{med:.2f} s (min {times[0]:.2f} s)"}
 
 
 def cpu_baseline(workload: str, seconds: float, phase: str = "pretrain") -> dict:
     """Run the CPU leg in a child process with a hard wall-clock cap so the default bench always finishes in minutes."""
     import subprocess
 
-    cap = 6 * seconds + 60
+    cap = 8 * seconds + 90
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", workload, "--cpu-seconds", str(seconds),
            "--phase", phase]
     env = dict(os.environ, OMP_NUM_THREADS=str(host_cores()), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
@@ -230,8 +241,9 @@ def main() -> None:
             dist.init_process_group(args.backend)
 
     torch.set_num_threads(min(4, host_cores()))   # host-side torch ops are tiny (mask draws); a 128-thread pool only adds latency
-    torch.manual_seed(42 + rank)
+    torch.manual_seed(42)            # identical initial weights on every rank (the loops also broadcast rank 0's)
     ds, model = build_model(args.config, args.phase)
+    torch.manual_seed(42 + rank)     # per-rank mask draws from here on
     if args.phase == "pretrain":
         loop = PretrainLoop(model, args.batch, dev, loss=args.loss, total_steps=args.steps + args.warmup, world_size=world,
                             exchange=True if args.rehearse_exchange else None,
@@ -272,26 +284,35 @@ def main() -> None:
     sync()
     wait0 = getattr(loop.engine, "host_wait_s", 0.0)
     t0 = time.perf_counter()
+    marks = []                # one event per step boundary: per-step GPU times (min / median) without any host sync
     for _ in range(args.steps):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append(ev)
         loss = loop.step(batch)
     flush()   # the K-th optimizer update belongs to the timed region: K forwards, K backwards, K AdamW updates
     # host time spent ISSUING the steps (diagnostic: host-bound if ~= elapsed): the time blocked on the mask staging
     # ring's back-pressure (host >= 4 steps ahead of the GPU) is not issue work and is taken out
     t_issue = time.perf_counter() - t0 - (getattr(loop.engine, "host_wait_s", 0.0) - wait0)
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    marks.append(ev)
     sync()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(a.elapsed_time(b) for a, b in zip(marks, marks[1:]))
     loss_val = float(loss.item())   # the engine's loss buffer is static: read it before the roofline leg runs more steps
     # Roofline leg: the same steps once more with HIP events around every MFMA-kernel launch on its stream (event
     # pairs cannot be recorded inside a captured graph, so these steps are launched eagerly; kernels are identical).
     timer = None if args.no_kernel_timing else hip.KernelTimer()
     if timer is not None:
+        saved_ms = loop.engine.multi_stream
         loop.engine.multi_stream = False   # one kernel at a time, so each event pair brackets exactly one launch
         hip.set_kernel_timer(timer)
         for _ in range(args.steps):
             loop.step(batch)
         flush()
         hip.set_kernel_timer(None)
-        loop.engine.multi_stream = True
+        loop.engine.multi_stream = saved_ms
         sync()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -307,6 +328,8 @@ def main() -> None:
         out = {
             "metric": f"MAE-{args.phase} tiles/sec", "value": round(value, 2), "unit": "tiles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "step_ms": {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3),
+                        "max": round(step_ms[-1], 3), "how": "HIP events on the main stream at every step boundary (this rank)"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic" if not args.from_host else "synthetic, fed from pinned host memory every step (PCIe-inclusive)",
             "config": {"workload": f"{args.config}: {w['desc']}", "tiles_per_gpu": args.batch,

@@ -253,6 +253,9 @@ int mh_colsum(const void* x, int x_is_f32, float* out, int M, int N, int ld, voi
 /* Zero n_spans (offset, length) float ranges of one buffer (spans: device array of 2*n_spans longs; max_len = longest span).
  * Used to clear only the atomically accumulated gradient slots when the weight gradients are stored by the grouped GEMM. */
 int mh_zero_spans(float* base, const long* spans_device, int n_spans, long max_len, void* stream);
+/* x[0..n) *= *scale with the scalar read on the device; a no-op when it equals 1 (the autograd bridge of the Lightning
+ * surface, maestro/train/base.py:242-247: loss.backward() hands over d loss as a device tensor). */
+int mh_scale_dev(float* x, long n, const float* scale, void* stream);
 /* f32 -> bf16 cast of a flat buffer (weight shadow copies). */
 int mh_cast_bf16(const float* src, void* dst, long n, void* stream);
 /* f32 [E, K] -> bf16 [E, Kpad] (zero padded rows: patch-embed conv weight [E, C*P*P]) and the transpose for grads:

@@ -153,7 +153,27 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, c
     adamw_update(p, g, m, v, pb, n, hyper[0], b1, b2, eps, wd, hyper[1], hyper[2], hyper[3]);
 }
 
+// x *= *scale, skipped when the device scalar is exactly 1 (loss.backward() with autograd's default ones gradient): the
+// Lightning bridge scales the flat gradient buffer by d loss without reading the scalar on the host.
+__global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, long n, const float* __restrict__ scale) {
+    const float s = *scale;
+    if (s == 1.f) return;
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        *reinterpret_cast<f32x4*>(x + i) = *reinterpret_cast<const f32x4*>(x + i) * s;
+    } else {
+        for (long j = i; j < n; ++j) x[j] *= s;
+    }
+}
+
 }  // namespace
+
+extern "C" int mh_scale_dev(float* x, long n, const float* scale, void* stream) {
+    MH_CHECK_ARG(x && scale && n > 0 && ((uintptr_t)x % 16) == 0, "mh_scale_dev: bad arguments (x 16-byte aligned)");
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, scale);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int mh_masked_loss(const float* rec, const float* target, const uint8_t* mask_group, const int* n_masked,
                               float weight, float* acc, void* drec, int B, int Lm, int Lgroup, int tok_off, int PPC, int p,

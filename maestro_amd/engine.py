@@ -49,7 +49,12 @@ class ParamStore:
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
         self.flat = torch.zeros(off, dtype=F32, device=device)
-        self.grad = torch.zeros(off, dtype=F32, device=device)
+        # gradient buffer + one trailing slot block: ``extra[0]`` carries the step's scalar loss through the data-parallel
+        # exchange (it rides in the first bucket: the tail of the buffer is what backward completes first), so the cross-rank
+        # mean loss of ``logger.py:268-276`` costs neither a collective of its own nor a host read
+        self.grad_all = torch.zeros(off + ALIGN, dtype=F32, device=device)
+        self.grad, self.extra = self.grad_all[:off], self.grad_all[off:]
+        self.fresh = True          # no backward has written ``grad`` yet (the views attached below are not gradients)
         self.half = torch.zeros(off, dtype=BF16, device=device)
         for p in self.params:
             o = self.offset[id(p)]
@@ -72,9 +77,15 @@ class ParamStore:
         ends = [self.offset[id(p)] + (p.numel() + ALIGN - 1) // ALIGN * ALIGN for p in params]
         return min(offs), max(ends)
 
+    def _versions(self):
+        """Staleness key of the bf16 shadow.  ``p.data = view`` does NOT make a parameter share ``flat``'s version counter:
+        ``torch.optim.AdamW.step()``, ``load_state_dict`` and ``p.add_()`` bump ``p._version`` only, writes through ``flat``
+        (``swapped``, ``broadcast``) bump ``flat._version`` only -- so the key covers both."""
+        return self.flat._version, sum(p._version for p in self.params)
+
     def refresh_half(self, force: bool = False) -> bool:
         """Re-cast the bf16 shadow when the fp32 parameters were modified outside the engine."""
-        v = self.flat._version
+        v = self._versions()
         if force or v != self._version:
             hip.cast_bf16(self.flat, self.half, self.total)
             self._version = v
@@ -82,7 +93,7 @@ class ParamStore:
         return False
 
     def mark_synced(self) -> None:
-        self._version = self.flat._version
+        self._version = self._versions()
 
     def flat_from(self, other: nn.Module, own: nn.Module) -> torch.Tensor:
         """A flat fp32 GPU buffer in THIS store's layout holding the parameters of ``other``, a structural copy of the
@@ -603,11 +614,15 @@ class MAEEngine(EngineBase):
         if (opt.lo, opt.hi) != (0, ps.total):
             raise ValueError("the overlapped optimizer expects an optimizer over the whole flat buffer")
         stages: dict = {}
+        seen_spans = set()
 
         def add(key, params):
             params = list(params)
             if params:
-                stages.setdefault(key, []).append(ps.span(params))
+                sp = ps.span(params)
+                if sp not in seen_spans:        # an encoder / decoder holder shared by several groups is added once
+                    seen_spans.add(sp)
+                    stages.setdefault(key, []).append(sp)
 
         for name in m.patch_embed:
             add(("embed", 0), m.patch_embed[name].parameters())

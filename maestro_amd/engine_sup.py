@@ -262,7 +262,13 @@ class SupervisedEngine(EngineBase):
         with self._tuning_pass("backward"):
             self._segment(f"sup_bwd_heads:{self.phase}", key, self._bwd_heads)
             if self.phase == "finetune":
-                self._segment("sup_bwd_encoder", key, self._bwd_encoder)
+                # with a gradient hook (data parallel) the joint encoder is a launch segment of its own: its finished slice --
+                # and the heads' -- go to the all-reduce while the group encoders' backward still runs
+                if self.grad_hook is not None and self.joint is not None:
+                    self._segment("sup_bwd_joint:h", key, lambda: self._bwd_encoder("joint"))
+                    self._segment("sup_bwd_encoder:h", key, lambda: self._bwd_encoder("groups"))
+                else:
+                    self._segment("sup_bwd_encoder", key, lambda: self._bwd_encoder("all"))
 
     def _bwd_heads(self) -> None:
         m, E, B, ps = self.model, self.E, self.B, self.store  # noqa: N806
@@ -375,18 +381,34 @@ class SupervisedEngine(EngineBase):
                 self._defer = False
         return self._defer
 
-    def _bwd_encoder(self) -> None:
+    def _deferred_tables(self, part: str, stacks: list):
+        tabs = self.__dict__.setdefault("_wgrad_tables", {})
+        if part not in tabs:
+            tabs[part] = (hip.ColsumBatch([j for st in stacks for j in st.reduce_jobs()], self.device),
+                          hip.GroupedTN([p for st in stacks for p in st.wgrad_problems()], self.device))
+        return tabs[part]
+
+    def _bwd_encoder(self, part: str = "all") -> None:
+        """``part``: "all" (one segment), or "joint" followed by "groups" (two segments, see ``backward``)."""
         m, E, B, ps = self.model, self.E, self.B, self.store  # noqa: N806
         AT = hip.OUT_F32 | hip.ATOMIC  # noqa: N806
         defer = self._wgrad_deferred()
-        src = self.dxenc
-        if self.joint is not None:
-            jt, R = self.joint, B * self.JL  # noqa: N806
-            jn = jt.t.norm
-            hip.layernorm_bwd(self.dxenc, R, 0, jt.x_last, R, 0, jn.weight, self.mean_j, self.rstd_j, None, jt.dxa, jt.top16,
-                              ps.g(jn.weight), ps.g(jn.bias), jt.top_bias_grad(), self.ln_ws, 1, R, E)
-            src, _ = jt.backward(jt.dxa, defer=defer)
-            self._grads_ready(jn)
+        if part in ("all", "joint"):
+            self._src = self.dxenc
+            if self.joint is not None:
+                jt, R = self.joint, B * self.JL  # noqa: N806
+                jn = jt.t.norm
+                hip.layernorm_bwd(self.dxenc, R, 0, jt.x_last, R, 0, jn.weight, self.mean_j, self.rstd_j, None, jt.dxa, jt.top16,
+                                  ps.g(jn.weight), ps.g(jn.bias), jt.top_bias_grad(), self.ln_ws, 1, R, E)
+                self._src, _ = jt.backward(jt.dxa, defer=defer, ready=not defer)
+                self._grads_ready(jn)
+            if part == "joint":
+                if defer:
+                    for tab in self._deferred_tables("joint", [self.joint]):
+                        tab.launch()
+                    self._grads_ready(m.encoder_inter)
+                return
+        src = self._src
 
         def side(g):
             def run():
@@ -394,7 +416,7 @@ class SupervisedEngine(EngineBase):
                 nrm, Lb = st.t.norm, self.Lb[g.name]  # noqa: N806
                 hip.layernorm_bwd(src, self.JL, self.goff[g.name], st.x_last, Lb, 0, nrm.weight, gbuf["mean_e"], gbuf["rstd_e"],
                                   None, st.dxa, st.top16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(), st.ln_ws, B, Lb, E)
-                dx0, _ = st.backward(st.dxa, defer=defer)
+                dx0, _ = st.backward(st.dxa, defer=defer, ready=False)
                 dxg = dx0.view(g.Beff, g.L, E)
                 for s in g.mods:
                     b = self.mb[s.name]
@@ -410,17 +432,14 @@ class SupervisedEngine(EngineBase):
 
         self._run_parallel([side(g) for g in self.groups])
         if defer:
-            stacks = list(self.enc.values()) + ([self.joint] if self.joint is not None else [])
-            if not hasattr(self, "_wgrad_table"):
-                self._wgrad_table = hip.GroupedTN([p for st in stacks for p in st.wgrad_problems()], self.device)
-                self._reduce_table = hip.ColsumBatch([j for st in stacks for j in st.reduce_jobs()], self.device)
-            self._reduce_table.launch()   # deferred LayerNorm / bias parameter gradients of the stacks (one launch)
-            self._wgrad_table.launch()
+            stacks = list(self.enc.values()) + ([self.joint] if (self.joint is not None and part == "all") else [])
+            for tab in self._deferred_tables(part, stacks):   # deferred LayerNorm / bias parameter gradients + weight gradients
+                tab.launch()
         for name in m.patch_embed:
             self._grads_ready(m.patch_embed[name])
         for name in m.encoder:
             self._grads_ready(m.encoder[name])
-        if m.encoder_inter is not None:
+        if m.encoder_inter is not None and part == "all":
             self._grads_ready(m.encoder_inter)
 
     # ------------------------------------------------------------------------------------------ outputs

@@ -369,6 +369,11 @@ def colsum(x, out, M, N, ld):
     call("mh_colsum", x, _I(1 if x.dtype == torch.float32 else 0), out, _I(M), _I(N), _I(ld))
 
 
+def scale_dev(x, n, scale):
+    """``x[:n] *= scale`` with ``scale`` a 1-element f32 device tensor (read on the device; no-op when it is 1)."""
+    call("mh_scale_dev", x, _L(n), scale)
+
+
 def cast_bf16(src, dst, n):
     call("mh_cast_bf16", src, dst, _L(n))
 
@@ -480,49 +485,6 @@ def kernel_timer_active() -> bool:
 
 
 _attn_fwd_raw, _attn_bwd_raw = attn_fwd, attn_bwd
-
-
-def layernorm_bwd_partial(dy, dy_L, dy_off, x, x_L, x_off, gamma, mean, rstd, dres, dx, dx_bf16, workspace, B, n, dim):
-    """LayerNorm backward that leaves (dgamma | dbeta | colsum(dx)) as per-block partial rows in ``workspace`` (see ColsumBatch)."""
-    call("mh_layernorm_bwd_partial", dy, _I(dy_L), _I(dy_off), _I(1 if dy.dtype == torch.float32 else 0), x, _I(x_L), _I(x_off),
-         gamma, mean, rstd, dres, dx, dx_bf16, workspace, _I(B), _I(n), _I(dim))
-
-
-COLSUM_ROWS = 16   # MH_COLSUM_ROWS in include/maestro_hip.h
-
-
-class _MhColsumJob(ctypes.Structure):
-    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
-                ("ld", ctypes.c_int), ("reserved", ctypes.c_int)]
-
-
-class ColsumBatch:
-    """Descriptor table (built once: all buffers are static) for ``mh_colsum_batched``: jobs ``(src f32 [rows, ld], dst f32
-    [cols], rows, cols, ld)`` -> ``dst += column sums of src``, all in one launch."""
-
-    def __init__(self, jobs, device) -> None:
-        if not jobs:
-            raise HipExtensionError("ColsumBatch: no jobs")
-        arr = (_MhColsumJob * len(jobs))()
-        for i, (src, dst, rows, cols, ld) in enumerate(jobs):
-            if src.dtype != torch.float32 or dst.dtype != torch.float32 or not src.is_cuda or not dst.is_cuda:
-                raise HipExtensionError("ColsumBatch: f32 device tensors expected")
-            if rows <= 0 or cols <= 0 or ld < cols or src.numel() < (rows - 1) * ld + cols or dst.numel() < cols:
-                raise HipExtensionError(f"ColsumBatch job {i}: shape ({rows}, {cols}, ld {ld}) does not fit its buffers")
-            arr[i] = _MhColsumJob(src.data_ptr(), dst.data_ptr(), rows, cols, ld, 0)
-        self.keep = [t for job in jobs for t in job[:2]]     # the descriptors hold raw pointers
-        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
-        blocks = []                                          # one work item per workgroup: job << 48 | column block << 32 | row chunk
-        for i, (_, _, rows, cols, _) in enumerate(jobs):
-            if cols > 65535 * 256 or len(jobs) > 32767:
-                raise HipExtensionError("ColsumBatch: too many jobs / columns for the work-item encoding")
-            for cb in range(-(-cols // 256)):
-                blocks += [(i << 48) | (cb << 32) | rc for rc in range(-(-rows // COLSUM_ROWS))]
-        self.blocks = torch.tensor(blocks, dtype=torch.int64).to(device)
-        self.n, self.n_blocks = len(jobs), len(blocks)
-
-    def launch(self) -> None:
-        call("mh_colsum_batched", self.table, _I(self.n), self.blocks, _I(self.n_blocks))
 
 
 def attn_fwd(qkv, out, lse, B, N, H, D, scale):  # noqa: F811

@@ -6,6 +6,15 @@ sharded over ranks (one process per GPU) and the only exchange is the gradient s
 engine reports them final -- the engine's flat layout follows forward order, so backward completes it tail first and
 the buckets grow from the end of the buffer towards the start.  The sum is turned into the mean by folding
 ``1/world_size`` into the optimizer's ``grad_scale`` (no extra pass).
+
+What Lightning's DDP wrap does besides the reducer is reproduced explicitly:
+
+* ``broadcast_parameters``: every rank starts from rank 0's weights (DDP broadcasts the module state at construction);
+* the per-step scalar loss mean (``pl_module.log(..., sync_dist=True)``, ``maestro/train/logger.py:252-276``) rides in
+  the trailing slot of the gradient buffer -- part of the FIRST bucket, no collective of its own, no host read;
+* ``EngineDDPCallback``: the same exchange for a Lightning ``Trainer`` that runs ``SSLModule`` with a single-device
+  strategy per process (the engine writes ``p.grad`` by hand, so ``DistributedDataParallel``'s autograd hooks never fire
+  and a DDP-wrapped module would not be reduced).
 """
 
 from __future__ import annotations
@@ -14,19 +23,44 @@ import torch
 import torch.distributed as dist
 
 
+def _active(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def broadcast_parameters(engine, group=None, src: int = 0) -> None:
+    """All ranks take rank ``src``'s parameters (one broadcast of the flat fp32 buffer) and rebuild the bf16 shadows."""
+    if not _active(group) or dist.get_world_size(group) == 1:
+        return
+    dist.broadcast(engine.store.flat, src, group=group)
+    engine.store.refresh_half(force=True)
+    engine._pack_conv_weights()
+
+
 class GradSync:
-    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 64 << 20, group=None) -> None:
+    """``flat_grad``: the buffer to exchange.  ``always_ready_from``: elements from that offset on are final before the
+    backward starts (the engine's trailing scalar slot: ``ParamStore.grad_all[total:]``).  ``bucket_dtype=torch.bfloat16``
+    (opt-in: halves the xGMI bytes, rounds every gradient to 8 significant bits before the sum) stages each bucket
+    through a bf16 copy; the trailing slot is always exchanged in fp32."""
+
+    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 64 << 20, group=None, always_ready_from: int | None = None,
+                 bucket_dtype: torch.dtype | None = None) -> None:
         self.grad, self.group = flat_grad, group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.world = dist.get_world_size(group) if _active(group) else 1
         # a one-rank group still exchanges when it exists: `bench.py --rehearse-exchange` drives the RCCL launch plan on one GPU
-        self.exchange = dist.is_available() and dist.is_initialized()
-        self.bucket = max(1, bucket_bytes // flat_grad.element_size())
+        self.exchange = _active(group)
+        self.payload = flat_grad.numel() if always_ready_from is None else always_ready_from
+        self.half = bucket_dtype is not None and bucket_dtype != flat_grad.dtype
+        self.bucket_dtype = bucket_dtype
+        self.bucket = max(1, bucket_bytes // (2 if self.half else flat_grad.element_size()))
+        self._stage: dict = {}
         self.launched: list[tuple[int, int]] = []
         self.begin()
 
     def begin(self) -> None:
         self.frontier = self.grad.numel()   # everything >= frontier is already in flight
         self.ready_iv: list[tuple[int, int]] = []
+        if self.payload < self.grad.numel():
+            self.ready_iv.append((self.payload, self.grad.numel()))
         self.works = []
         self.launched = []
 
@@ -34,8 +68,29 @@ class GradSync:
         if hi <= lo:
             return
         self.launched.append((lo, hi))
-        if self.exchange:
-            self.works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if not self.exchange:
+            return
+        if self.half and hi > self.payload:      # the scalar slot stays fp32: split it off
+            self.works.append((dist.all_reduce(self.grad[self.payload:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                               async_op=True), None))
+            hi = self.payload
+            if hi <= lo:
+                return
+        if self.half:
+            st = self._stage.get((lo, hi))
+            if st is None:
+                st = self._stage[(lo, hi)] = torch.empty(hi - lo, dtype=self.bucket_dtype, device=self.grad.device)
+            st.copy_(self.grad[lo:hi])
+            self.works.append((dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True), (lo, hi, st)))
+        else:
+            self.works.append((dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
+
+    def _wait(self, item) -> None:
+        work, back = item
+        work.wait()
+        if back is not None:
+            lo, hi, st = back
+            self.grad[lo:hi].copy_(st)
 
     def ready(self, lo: int, hi: int) -> None:
         """Engine hook: ``grad[lo:hi]`` will not be written again in this backward."""
@@ -61,7 +116,7 @@ class GradSync:
         self._launch(0, self.frontier)
         self.frontier = 0
         for w in self.works:
-            w.wait()
+            self._wait(w)
         self.works = []
         return 1.0 / self.world
 
@@ -75,11 +130,50 @@ class GradSync:
         self.frontier = 0
         tail = self.works.pop() if (self.works and split > 0) else None
         for w in self.works:
-            w.wait()
+            self._wait(w)
         self.works = []
 
         def wait_tail():
             if tail is not None:
-                tail.wait()
+                self._wait(tail)
 
         return 1.0 / self.world, (split if tail is not None else 0), wait_tail
+
+
+class EngineDDPCallback:
+    """Lightning recipe for several GPUs (duck-typed ``pytorch_lightning.Callback``: only the hooks below are used).
+
+    Run the ``Trainer`` with ONE device per process (``strategy="auto", devices=1`` under ``torchrun``, process group
+    initialised by the launcher) and add this callback: it broadcasts rank 0's weights once the engine exists and sums the
+    engine's flat gradient buffer after every backward, before the optimizer step reads ``p.grad``.  ``DistributedDataParallel``
+    itself cannot be used: the engine's gradients do not come from autograd hooks."""
+
+    def __init__(self, bucket_mb: int = 64, group=None) -> None:
+        self.bucket_bytes, self.group, self._sync, self._engine = bucket_mb << 20, group, None, None
+
+    def _attach(self, engine) -> None:
+        if engine is self._engine:
+            return
+        self._engine = engine
+        broadcast_parameters(engine, self.group)
+        self._sync = GradSync(engine.store.grad_all, self.bucket_bytes, self.group, always_ready_from=engine.store.total)
+
+    def _engine_of(self, pl_module):
+        return getattr(pl_module.model, "_engine", None) or getattr(pl_module.model, "_sup_engine", None)
+
+    def on_train_batch_start(self, trainer, pl_module, batch, batch_idx) -> None:  # noqa: ARG002
+        engine = self._engine_of(pl_module)
+        if engine is not None and _active(self.group):
+            self._attach(engine)       # (the engine exists from the first training_step on: weights are synchronised at step 1)
+
+    def on_after_backward(self, trainer, pl_module) -> None:  # noqa: ARG002
+        """The exchange is NOT overlapped with the backward here: the autograd bridge may still rescale / accumulate the
+        buffer after the engine's backward (``_EngineLoss.backward``), so the buckets go out once it has returned."""
+        engine = self._engine_of(pl_module)
+        if engine is None or not _active(self.group):
+            return
+        self._attach(engine)
+        self._sync.begin()
+        scale = self._sync.finish()
+        if scale != 1.0:
+            engine.store.grad.mul_(scale)     # torch optimizers read p.grad: the mean must be in the buffer itself

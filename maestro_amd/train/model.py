@@ -17,6 +17,7 @@ from types import SimpleNamespace
 import torch
 from torch import nn
 
+from maestro_amd import hip
 from maestro_amd.ssl.mae import mae_large, mae_medium, mae_small, mae_tiny
 
 try:  # optional dependency, exactly as in the reference's environment
@@ -34,21 +35,44 @@ except Exception:  # noqa: BLE001
 
 
 class MeanMetric(nn.Module):
-    """Minimal stand-in for ``torchmetrics.MeanMetric`` (running mean of a scalar; ``base.py:52-56``)."""
+    """Minimal stand-in for ``torchmetrics.MeanMetric`` (running mean of a scalar; ``base.py:52-56``).
+
+    ``update`` accumulates ON THE DEVICE the value lives on (no ``float(tensor)``: a host read would stall the launch
+    run-ahead on every ``training_step``); only ``compute`` synchronises.  Under ``torch.distributed`` ``compute`` sums
+    (total, count) over the ranks, as torchmetrics does when Lightning reads the metric at epoch end
+    (``maestro/train/logger.py:184-230``)."""
 
     def __init__(self) -> None:
         super().__init__()
-        self.total, self.count = 0.0, 0
+        self._sum, self._host, self.count = None, 0.0, 0
 
     def update(self, value) -> None:
-        self._pending = value.detach() if isinstance(value, torch.Tensor) else value
-        self.total, self.count = self.total + float(self._pending), self.count + 1
+        if isinstance(value, torch.Tensor):
+            v = value.detach().reshape(()).to(torch.float32)
+            if self._sum is None or self._sum.device != v.device:
+                self._host += float(self._sum) if self._sum is not None else 0.0
+                self._sum = torch.zeros((), dtype=torch.float32, device=v.device)
+            self._sum.add_(v)
+        else:
+            self._host += float(value)
+        self.count += 1
+
+    @property
+    def total(self) -> float:
+        return self._host + (float(self._sum) if self._sum is not None else 0.0)
 
     def compute(self) -> float:
-        return self.total / max(self.count, 1)
+        total, count = self.total, float(self.count)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dev = self._sum.device if (self._sum is not None and dist.get_backend() == "nccl") else "cpu"
+            t = torch.tensor([total, count], dtype=torch.float64, device=dev)
+            dist.all_reduce(t)
+            total, count = float(t[0]), float(t[1])
+        return total / max(count, 1.0)
 
     def reset(self) -> None:
-        self.total, self.count = 0.0, 0
+        self._sum, self._host, self.count = None, 0.0, 0
 
 
 class _EngineLoss(torch.autograd.Function):
@@ -67,16 +91,22 @@ class _EngineLoss(torch.autograd.Function):
         # Gradient accumulation (Lightning's accumulate_grad_batches, ``conf/trainer.py``): the engine STORES its gradients,
         # so when the previous micro-batch's gradients are still attached (no zero_grad in between) they are set aside
         # and added back after this backward -- autograd's "+=" semantics at the cost of one pass over the flat buffer.
-        live = any(p.grad is not None and p.grad.data_ptr() == st.g(p).data_ptr() for p in st.params
-                   if lo <= st.offset[id(p)] < hi)
+        # (``st.fresh``: nothing has been written to the buffer yet -- the views ParamStore pre-attaches are not gradients.)
+        live = not st.fresh and any(p.grad is not None and p.grad.data_ptr() == st.g(p).data_ptr() for p in st.params
+                                    if lo <= st.offset[id(p)] < hi)
         if live:
             if getattr(st, "grad_acc", None) is None:
                 st.grad_acc = torch.empty_like(st.grad)
             st.grad_acc.copy_(st.grad)
         eng.zero_grad()
         eng.backward()
-        if not (isinstance(grad_out, torch.Tensor) and grad_out.numel() == 1 and float(grad_out) == 1.0):
-            st.grad.mul_(grad_out.reshape(()))  # loss / accumulate_grad_batches, or a trainer's loss scaling
+        st.fresh = False
+        if isinstance(grad_out, torch.Tensor) and grad_out.is_cuda:
+            # d loss as a device scalar (autograd's ones, loss / accumulate_grad_batches, a trainer's loss scaling): applied on
+            # the device, skipped there when it is 1 -- no host read of the value
+            hip.scale_dev(st.grad, st.total, grad_out.detach().reshape(1).to(torch.float32))
+        elif float(grad_out) != 1.0:
+            st.grad.mul_(float(grad_out))
         if live:
             st.grad.add_(st.grad_acc)
         for p in st.params:  # re-attach views if the trainer cleared them (zero_grad(set_to_none=True))

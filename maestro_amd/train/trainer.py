@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import torch
 
-from maestro_amd.train.ddp import GradSync
+from maestro_amd.train.ddp import GradSync, broadcast_parameters
 from maestro_amd.train.optim import FusedAdamW, OneCycle, scaled_lr
 
 
@@ -32,14 +32,19 @@ class PretrainLoop:
     def __init__(self, model, batch_size: int, device, loss: str = "l2_norm", base_lr: float = 3e-5,
                  betas=(0.9, 0.99), weight_decay: float = 0.01, total_steps: int = 1000, world_size: int = 1,
                  final_factor: float = 1e7, bucket_mb: int = 64, exchange: bool | None = None,
-                 accumulate: int = 1, overlap_optimizer: bool = False) -> None:
+                 accumulate: int = 1, overlap_optimizer: bool = False, bucket_dtype=None) -> None:
         self.engine = model.engine(batch_size, device, loss=loss)
+        broadcast_parameters(self.engine)   # every rank starts from rank 0's weights (what Lightning's DDP wrap does)
         lr = scaled_lr(base_lr, batch_size, accumulate, 1, world_size)   # model.py:120-128: micro-batches count towards the batch
         self.sched = OneCycle(lr, max(total_steps, 2), pct_start=0.2, div_factor=1000.0,
                               final_div_factor=final_factor / 1000.0)
         self.opt = FusedAdamW(self.engine, lr, betas=betas, weight_decay=weight_decay)
         exchange = world_size > 1 if exchange is None else exchange   # True at world_size 1: one-rank rehearsal of the launch plan
-        self.sync = GradSync(self.engine.store.grad, bucket_bytes=bucket_mb << 20) if exchange else None
+        st = self.engine.store
+        # the buffer handed to the exchange ends with the scalar slot that carries the step's loss (first bucket)
+        self.sync = GradSync(st.grad_all, bucket_bytes=bucket_mb << 20, always_ready_from=st.total,
+                             bucket_dtype=bucket_dtype) if exchange else None
+        self.world = world_size
         if self.sync is not None:
             self.engine.grad_hook = self.sync.ready
         # opt-in: AdamW of step t runs inside the forward of step t+1 (per-layer stages on a side stream, captured with the
@@ -79,6 +84,7 @@ class PretrainLoop:
         eng.zero_grad()
         scale = 1.0
         if self.sync is not None:
+            eng.store.extra[:1].copy_(loss)     # the loss rides in the first gradient bucket (see ``loss_mean``)
             self.sync.begin()
         eng.backward()
         if self.sync is not None:   # the last bucket (encoder head + patch embed) is reduced under the first AdamW launch
@@ -88,6 +94,15 @@ class PretrainLoop:
             self._optimizer_step(scale)
         self.it += 1
         return loss
+
+    @property
+    def loss_mean(self) -> torch.Tensor:
+        """Cross-rank mean of the last step's loss as a device tensor (the value ``pl_module.log(..., sync_dist=True)`` logs
+        every step, ``maestro/train/logger.py:268-276``): summed inside the first gradient bucket, read without a host sync
+        on the step path.  Without an exchange it is the local loss."""
+        if self.sync is None:
+            return self.engine.loss_acc
+        return self.engine.store.extra[:1] / self.sync.world
 
     def _step_accumulated(self, micro: list) -> torch.Tensor:
         """The engine stores (does not add) its gradients, so micro-batches are summed in a second flat buffer (one
@@ -111,6 +126,7 @@ class PretrainLoop:
             eng.grad_hook = hook
         scale = 1.0 / len(micro)
         if self.sync is not None:
+            eng.store.extra[:1].copy_(loss)
             self.sync.begin()
             scale *= self.sync.finish()
         self._optimizer_step(scale)
@@ -124,26 +140,44 @@ class SupervisedLoop:
 
     def __init__(self, model, batch_size: int, device, phase: str = "finetune", base_lr: float = 3e-5, betas=(0.9, 0.99),
                  weight_decay: float = 0.01, total_steps: int = 1000, world_size: int = 1, final_factor: float = 1e7,
-                 bucket_mb: int = 64) -> None:
+                 bucket_mb: int = 64, exchange: bool | None = None, bucket_dtype=None) -> None:
         self.engine = model.sup_engine(batch_size, device, phase)
+        broadcast_parameters(self.engine)
         lr = scaled_lr(base_lr, batch_size, 1, 1, world_size)
         self.sched = OneCycle(lr, max(total_steps, 2), pct_start=0.2, div_factor=1000.0,
                               final_div_factor=final_factor / 1000.0)
         self.opt = FusedAdamW(self.engine, lr, betas=betas, weight_decay=weight_decay)
         lo, hi = self.engine.trainable_span
-        self.sync = GradSync(self.engine.store.grad[lo:hi], bucket_bytes=bucket_mb << 20) if world_size > 1 else None
+        st = self.engine.store
+        exchange = world_size > 1 if exchange is None else exchange
+        # buckets cover [lo, total + slot): probe exchanges the heads only (the frozen encoder has no gradients)
+        self.lo = lo
+        self.sync = GradSync(st.grad_all[lo:], bucket_bytes=bucket_mb << 20, always_ready_from=st.total - lo,
+                             bucket_dtype=bucket_dtype) if exchange else None
+        if self.sync is not None:      # finished slices (heads, joint encoder) go out while the rest of the backward runs
+            self.engine.grad_hook = lambda a, b: self.sync.ready(max(a, lo) - lo, b - lo) if b > lo else None
         self.it = 0
+
+    @property
+    def loss_mean(self) -> torch.Tensor:
+        if self.sync is None:
+            return self.engine.loss_acc
+        return self.engine.store.extra[:1] / self.sync.world
 
     def step(self, batch: dict) -> torch.Tensor:
         eng = self.engine
         loss = eng.forward(batch)
         eng.zero_grad()
-        eng.backward()
         scale = 1.0
-        if self.sync is not None:      # one exchange after the backward (the supervised phases are short fine-tuning runs)
+        if self.sync is not None:
+            eng.store.extra[:1].copy_(loss)
             self.sync.begin()
-            scale = self.sync.finish()
-        self.opt.step(lr=self.sched.lr(self.it), grad_scale=scale)
+        eng.backward()
+        if self.sync is not None:      # the head of the buffer (reduced last) is exchanged under the first AdamW launch
+            scale, split, wait_tail = self.sync.finish_split()
+            self.opt.step(lr=self.sched.lr(self.it), grad_scale=scale, split=split + self.lo if split else 0, between=wait_tail)
+        else:
+            self.opt.step(lr=self.sched.lr(self.it), grad_scale=scale)
         self.it += 1
         return loss
 

@@ -90,3 +90,90 @@ def test_gradsync_single_process_is_identity():
     sync = GradSync(grad, bucket_bytes=16)
     sync.ready(4, 10)
     assert sync.finish() == 1.0 and torch.equal(grad, torch.arange(10.0))
+
+
+class _FakeStore:
+    """The slice of ``ParamStore`` the exchange helpers touch (no GPU in these tests)."""
+
+    def __init__(self, n, rank):
+        self.total = n
+        self.flat = torch.full((n,), float(rank + 1))
+        self.grad_all = torch.zeros(n + 64)
+        self.grad, self.extra = self.grad_all[:n], self.grad_all[n:]
+        self.refreshed = 0
+
+    def refresh_half(self, force=False):
+        self.refreshed += 1
+
+
+class _FakeEngine:
+    def __init__(self, n, rank):
+        self.store, self.packed, self.grad_hook = _FakeStore(n, rank), 0, None
+
+    def _pack_conv_weights(self):
+        self.packed += 1
+
+
+def _slot_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+
+    from maestro_amd.train.ddp import EngineDDPCallback, GradSync, broadcast_parameters
+    from maestro_amd.train.model import MeanMetric
+    n = 1000
+    eng = _FakeEngine(n, rank)
+    st = eng.store
+    broadcast_parameters(eng)                                   # rank 0's weights everywhere, shadows rebuilt
+    bcast_ok = bool((st.flat == 1.0).all()) and st.refreshed == 1 and eng.packed == 1
+    res = {}
+    for tag, dt in (("f32", None), ("bf16", torch.bfloat16)):
+        st.grad.copy_(torch.randn(n, generator=torch.Generator().manual_seed(rank)))
+        st.extra.zero_()
+        st.extra[0] = 10.0 * (rank + 1)                          # this rank's loss
+        mine = st.grad.clone()
+        sync = GradSync(st.grad_all, bucket_bytes=(2 if dt else 4) * 300, always_ready_from=n, bucket_dtype=dt)
+        sync.begin()
+        sync.ready(600, 1000)                                    # first bucket: [600, n + 64) -- the slot rides along
+        first = list(sync.launched)
+        sync.ready(0, 600)
+        scale = sync.finish()
+        other = torch.randn(n, generator=torch.Generator().manual_seed(1 - rank))
+        want = mine + other if dt is None else (mine.bfloat16() + other.bfloat16()).float()   # bf16 buckets round first
+        tol = 0.0 if dt is None else 2e-2
+        res[tag] = (first, float((st.grad - want).abs().max()) <= tol * float(want.abs().max()) + 1e-6,
+                    float(st.extra[0] * scale))
+    # Lightning recipe: one all-reduce + mean after the backward, through the callback's hooks
+    cb = EngineDDPCallback(bucket_mb=1)
+    mod = SimpleNamespace(model=SimpleNamespace(_engine=eng, _sup_engine=None))
+    st.flat.fill_(float(rank + 5))
+    st.grad.fill_(float(rank + 1))
+    cb.on_train_batch_start(None, mod, None, 0)
+    cb.on_after_backward(None, mod)
+    cb_ok = bool((st.grad == 1.5).all()) and bool((st.flat == 5.0).all())
+    met = MeanMetric()
+    met.update(torch.tensor(float(rank + 1)))
+    met.update(3.0 * (rank + 1))
+    out.put((rank, bcast_ok, res, cb_ok, met.compute(), met.count))
+    dist.destroy_process_group()
+
+
+def test_loss_slot_bf16_buckets_callback_and_metric_two_ranks():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_slot_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, bcast_ok, per_mode, cb_ok, mean, count in res:
+        assert bcast_ok, f"rank {rank}: parameters were not taken from rank 0"
+        for tag, (first, grads_ok, loss_mean) in per_mode.items():
+            assert first == [(600, 1064)], (tag, first)          # the scalar slot is part of the FIRST bucket
+            assert grads_ok, (rank, tag)
+            assert abs(loss_mean - 15.0) < 1e-6, (tag, loss_mean)   # mean of 10 and 20, read from the exchanged slot
+        assert cb_ok, f"rank {rank}: callback did not average the gradients / broadcast the weights"
+        assert abs(mean - 3.0) < 1e-9 and count == 2             # (1 + 3 + 2 + 6) / 4 over both ranks

@@ -226,3 +226,34 @@ def test_lr_rule_counts_micro_batches_like_the_reference():
     assert scaled_lr(3e-5, 32, 1, 1, 1) == pytest.approx(3e-5 * (32 / 3) ** 0.5)
     assert scaled_lr(3e-5, 32, 4, 1, 8) == pytest.approx(3e-5 * (32 * 4 * 8 / 3) ** 0.5)
     assert scaled_lr(3e-5, 32, 2, 1, 1) == pytest.approx(scaled_lr(3e-5, 64, 1, 1, 1))
+
+
+def test_param_store_notices_updates_made_outside_the_engine(monkeypatch):
+    """``p.data = view`` does not share ``flat``'s version counter, so the staleness key of the bf16
+    shadow must include the parameters' own counters -- a torch optimizer step, ``load_state_dict`` and ``p.add_()`` all
+    have to trigger a re-cast, FusedAdamW's raw-pointer update (followed by ``mark_synced``) must not."""
+    import torch
+    from torch import nn
+
+    from maestro_amd import engine as eng_mod
+
+    casts = []
+    monkeypatch.setattr(eng_mod.hip, "cast_bf16", lambda src, dst, n: (casts.append(n), dst.copy_(src.to(dst.dtype))))
+    lin = nn.Linear(8, 4)
+    store = eng_mod.ParamStore(list(lin.named_parameters()), "cpu")
+    assert store.refresh_half() and len(casts) == 1 and not store.refresh_half()
+    opt = torch.optim.AdamW(lin.parameters(), lr=0.1)
+    lin.weight.grad.fill_(1.0)
+    opt.step()                                                   # bumps p._version only
+    assert store.refresh_half(), "optimizer step went unnoticed"
+    assert torch.equal(store.h(lin.weight).float(), lin.weight.detach().bfloat16().float())
+    lin.load_state_dict({k: torch.ones_like(v) for k, v in lin.state_dict().items()})
+    assert store.refresh_half(), "load_state_dict went unnoticed"
+    with torch.no_grad():
+        lin.bias.add_(1.0)
+    assert store.refresh_half() and not store.refresh_half()
+    store.flat.mul_(2.0)                                         # writes through the flat view bump flat._version only
+    assert store.refresh_half()
+    store.mark_synced()
+    assert not store.refresh_half()
+    assert store.fresh and store.grad_all.numel() == store.total + eng_mod.ALIGN and store.extra.numel() == eng_mod.ALIGN
