@@ -1027,6 +1027,24 @@ class MAEEngine(EngineBase):
                 out[s.name] = res
         return out
 
+    def logged_sample(self, name_mod: str):
+        """Sample ``[0, 0]`` of one modality for the image logs (``maestro/train/model.py:160-193`` keeps only that sample):
+        ``(target, rec, mask)`` as ``[C, S, S]`` tensors -- the returned (resized, elevation-rescaled) batch, the
+        reconstruction and the pixel-level mask.  Only that sample's L tokens are touched (a few tiny launches per step)."""
+        s = self.mods[name_mod]
+        g = next(g for g in self.groups if s in g.mods)
+        b = self.mb[name_mod]
+        rec = torch.empty(1, s.C, s.S, s.S, dtype=F32, device=self.device)
+        hip.depatchify(b["rec"][: s.L], rec, 1, s.C, s.S, s.P)           # tokens of (b = 0, d = 0) are rows [0, L)
+        tgt = self._staged[name_mod][0, 0]
+        if s.rescale_elev:
+            res = torch.empty(1, s.C, s.S, s.S, dtype=F32, device=self.device)
+            hip.rescale_elev(tgt.contiguous(), res, 1, s.C, s.S)
+            tgt = res[0]
+        tok = self.gb[g.name]["mask"][0, s.tok_off: s.tok_off + s.L].bool().reshape(1, s.g, 1, s.g, 1)
+        msk = tok.expand(s.C, s.g, s.P, s.g, s.P).reshape(s.C, s.S, s.S)
+        return tgt, rec[0], msk
+
     def token_masks(self) -> dict:
         """Per-group token masks ``{group: bool [Beff, L]}`` of the last forward."""
         return {g.name: self.gb[g.name]["mask"].bool() for g in self.groups}

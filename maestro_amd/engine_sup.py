@@ -457,6 +457,17 @@ class SupervisedEngine(EngineBase):
                 out[t] = hb["logits"].clone()
         return out
 
+    def logged_class_map(self, t: str) -> torch.Tensor:
+        """Arg-max class map ``[S, S]`` of sample 0 of a raster target (the image logs of ``base.py:58-96`` keep only that
+        sample): depatchifies that sample's g x g tokens only."""
+        hb = self.hb[t]
+        G, S = self.ref["G"], self.ref["G"] * hb["P"]  # noqa: N806
+        img = torch.empty(1, hb["C"], S, S, dtype=F32, device=self.device)
+        lg = hb["logits"][: G * G]
+        lg = lg if hb["PPCp"] == hb["PPC"] else lg[:, : hb["PPC"]].contiguous()
+        hip.depatchify(lg, img, 1, hb["C"], S, hb["P"])
+        return img[0].argmax(dim=0)
+
     def returned_batch(self, batch: dict) -> dict:
         """The reference returns the resized / elevation-rescaled batch (mim.py:425-437)."""
         out = dict(batch)

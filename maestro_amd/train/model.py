@@ -34,6 +34,65 @@ except Exception:  # noqa: BLE001
             return None
 
 
+# ---- checkpoint interchange with the reference: class paths inside the pickled hyper-parameters
+import contextlib  # noqa: E402
+import pickle  # noqa: E402
+import sys  # noqa: E402
+import types  # noqa: E402
+
+
+class _RenamingUnpickler(pickle.Unpickler):
+    """Resolves the reference's config classes (``maestro.conf.<...>.<Name>``) to ``maestro_amd.conf.<Name>`` when the
+    reference package is not importable -- a reference-written ``.ckpt`` then loads on a box that only has this repo."""
+
+    def find_class(self, module, name):
+        if module == "maestro" or module.startswith("maestro."):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                import maestro_amd.conf as ours
+                if module.startswith("maestro.conf") and hasattr(ours, name):
+                    return getattr(ours, name)
+                raise
+        return super().find_class(module, name)
+
+
+_RenamingPickle = types.SimpleNamespace(Unpickler=_RenamingUnpickler, load=lambda f, **kw: _RenamingUnpickler(f, **kw).load(),
+                                        __name__="pickle")
+
+
+@contextlib.contextmanager
+def _reference_class_paths():
+    """While a checkpoint is written: make ``maestro.conf.mask.MaskConfig`` resolvable for pickle (it only stores the
+    path + the field dict).  When the real reference is importable nothing is faked."""
+    try:
+        import maestro.conf.mask  # noqa: F401
+        yield
+        return
+    except Exception:  # noqa: BLE001
+        pass
+    from maestro_amd.conf import MaskConfig
+    fake = {}
+    for name in ("maestro", "maestro.conf", "maestro.conf.mask"):
+        if name not in sys.modules:
+            fake[name] = types.ModuleType(name)
+    ref_cls = type("MaskConfig", (MaskConfig,), {"__module__": "maestro.conf.mask", "__qualname__": "MaskConfig"})
+    sys.modules.update(fake)
+    sys.modules["maestro.conf.mask"].MaskConfig = ref_cls
+    try:
+        yield
+    finally:
+        for name in fake:
+            sys.modules.pop(name, None)
+
+
+def _as_reference_mask(mask):
+    cls = sys.modules["maestro.conf.mask"].MaskConfig
+    if isinstance(mask, cls):
+        return mask
+    return cls(**{f: getattr(mask, f) for f in cls.__dataclass_fields__})
+
+
 class MeanMetric(nn.Module):
     """Minimal stand-in for ``torchmetrics.MeanMetric`` (running mean of a scalar; ``base.py:52-56``).
 
@@ -161,31 +220,45 @@ class SSLModule(_Base):
 
     # ------------------------------------------------------------------ checkpoints (Lightning .ckpt layout)
     def checkpoint(self, **extra) -> dict:
-        """Lightning-style checkpoint dict: ``state_dict`` with the reference's keys + ``hyper_parameters``."""
+        """Lightning-style checkpoint dict: ``state_dict`` with the reference's keys + ``hyper_parameters`` as
+        ``save_hyperparameters(ignore=["datasets"])`` records them (``maestro/train/model.py:118``): the constructor
+        arguments, ``mask`` being the ``MaskConfig`` INSTANCE (``save_checkpoint`` pickles it under the reference's class
+        path so that the reference's ``load_from_checkpoint`` rebuilds its own dataclass)."""
         sd = {k: v.detach().cpu().clone() for k, v in self.state_dict().items() if k != "_anchor"}
-        hp = dict(interpolate=self.model.interpolate, fusion_mode=self.model.fusion_mode, inter_depth=self.model.inter_depth,
-                  model="mae", model_size=self._model_size, type_head=self._type_head, loss=self.loss_name,
-                  use_date_enc=self.model.fac_date_enc != 0.0, use_ema=self.ema_model is not None, mask=vars(self._mask))
-        return {"state_dict": sd, "hyper_parameters": hp, "pytorch-lightning_version": "maestro_amd", **extra}
+        hp = dict(mask=self._mask, interpolate=self.model.interpolate, fusion_mode=self.model.fusion_mode,
+                  inter_depth=self.model.inter_depth, model="mae", model_size=self._model_size, type_head=self._type_head,
+                  loss=self.loss_name, use_date_enc=self.model.fac_date_enc != 0.0, use_ema=self.ema_model is not None)
+        return {"state_dict": sd, "hyper_parameters": hp, "pytorch-lightning_version": "2.0.0", **extra}
 
     def save_checkpoint(self, path, **extra) -> None:
-        torch.save(self.checkpoint(**extra), path)
+        ckpt = self.checkpoint(**extra)
+        with _reference_class_paths():
+            ckpt["hyper_parameters"]["mask"] = _as_reference_mask(ckpt["hyper_parameters"]["mask"])
+            torch.save(ckpt, path)
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict: bool = False, datasets=None, **overrides):
         """Counterpart of ``LightningModule.load_from_checkpoint`` as the reference calls it
-        (``maestro/run_experiment.py:66-73``: ``strict=False, datasets=datasets``).  Reads reference checkpoints
-        (e.g. the HF ``MAESTRO_*_base`` weights): same keys, heads included; entries without a counterpart (``ema_model.*``
-        when ``use_ema`` is off, heads of targets that are filtered out) are skipped when ``strict=False``."""
+        (``maestro/run_experiment.py:66-73``: ``strict=False, datasets=datasets``).  Reads checkpoints the REFERENCE wrote
+        (e.g. the HF ``MAESTRO_*_base`` weights) without the reference being importable: their pickled hyper-parameters
+        name ``maestro.conf.mask.MaskConfig`` (``model.py:118``), which the unpickler resolves to this package's dataclass of
+        the same name.  Same keys, heads and ``ema_model.*`` included; entries without a counterpart (``ema_model.*`` when
+        ``use_ema`` is off, heads of targets that are filtered out) are skipped when ``strict=False``."""
         from maestro_amd.conf import MaskConfig
 
-        ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+        ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False,
+                          pickle_module=_RenamingPickle)
         hp = dict(ckpt.get("hyper_parameters", {}))
         hp.update(overrides)
         if datasets is None:
             raise ValueError("datasets must be given (it is excluded from the saved hyper-parameters, model.py:118)")
         mask = hp.pop("mask", None)
-        mask = MaskConfig(**mask) if isinstance(mask, dict) else (mask if mask is not None else MaskConfig())
+        if isinstance(mask, dict):
+            mask = MaskConfig(**mask)
+        elif mask is None:
+            mask = MaskConfig()
+        elif not isinstance(mask, MaskConfig):       # any object with the dataclass' fields
+            mask = MaskConfig(**{f: getattr(mask, f) for f in MaskConfig.__dataclass_fields__})
         hp = {k: v for k, v in hp.items() if k in ("interpolate", "fusion_mode", "inter_depth", "model", "model_size",
                                                    "type_head", "loss", "use_date_enc", "use_ema")}
         module = cls(datasets=datasets, mask=mask, **hp)
@@ -219,26 +292,22 @@ class SSLModule(_Base):
         self.metrics[f"loss_rec_{stage}"].update(loss)
         return loss
 
-    def compute_logs_rec(self, batch, engine, ssl_phase: str, stage: str):
-        """Visualisation tensors for sample [0, 0] only, built lazily (the reference recomputes them every step)."""
+    def compute_logs_rec(self, batch, engine, ssl_phase: str, stage: str):  # noqa: ARG002
+        """Visualisation tensors of sample ``[0, 0]`` (``maestro/train/model.py:160-193``): real ``[C, S, S]`` tensors, so
+        the reference's ``ImageLogger.to_numpy`` (``logger.py:52-59``: ``x.detach().cpu().numpy()``) consumes them
+        unchanged.  The reference evaluates three ``torch.where`` over the whole batch every step and then keeps one
+        sample; here only that sample is depatchified and blended.  Targets come from the RETURNED batch (resized,
+        elevation-rescaled: ``model.py:255-266``), not from the caller's."""
         log_inputs, log_preds, log_targets = {}, {}, {}
-
-        def lazy(kind, name_mod):
-            def make():
-                pixels, masks = engine.reconstructions()
-                msk, tgt, rec = masks[name_mod][0, 0], batch[name_mod][0, 0], pixels[name_mod][0, 0]
-                if kind == "input":
-                    out = torch.where(msk, torch.zeros_like(tgt), tgt)
-                    return torch.where(msk.all(dim=0, keepdim=True), torch.ones_like(tgt), out)
-                return torch.where(msk, rec, tgt) if kind == "rec" else tgt
-            return make
-
         for name_mod in self.model.mod_specs:
             if name_mod not in self.dataset.log_inputs:
                 continue
-            log_inputs[f"{ssl_phase}_{stage}/_{name_mod}_input"] = lazy("input", name_mod)
-            log_preds[f"{ssl_phase}_{stage}/_{name_mod}_rec"] = lazy("rec", name_mod)
-            log_targets[f"{ssl_phase}_{stage}/_{name_mod}_target"] = lazy("target", name_mod)
+            tgt, rec, msk = engine.logged_sample(name_mod)
+            inputs = torch.where(msk, torch.zeros_like(tgt), tgt)
+            inputs = torch.where(msk.all(dim=0, keepdim=True), torch.ones_like(tgt), inputs)
+            log_inputs[f"{ssl_phase}_{stage}/_{name_mod}_input"] = inputs
+            log_preds[f"{ssl_phase}_{stage}/_{name_mod}_rec"] = torch.where(msk, rec, tgt)
+            log_targets[f"{ssl_phase}_{stage}/_{name_mod}_target"] = tgt
         return log_inputs, log_preds, log_targets
 
     def pretrain_step(self, batch: dict, stage: str) -> dict:
@@ -256,16 +325,15 @@ class SSLModule(_Base):
         return loss
 
     def compute_logs_pred(self, batch, engine, ssl_phase: str, stage: str):
-        """Keys as ``base.py:58-96`` for the raster targets; values are built lazily and hold the class maps of sample
-        [0, 0] (the reference renders colour overlays with torchvision, which is logging, not arithmetic)."""
+        """Keys as ``base.py:58-96`` for the raster targets; values are tensors holding the class maps of sample [0, 0]
+        (the reference renders colour overlays of them with torchvision, which is logging, not arithmetic)."""
         log_inputs, log_preds, log_targets = {}, {}, {}
         for name_target, target in self.dataset.targets.items():
             if target.type_target != "segment":
                 continue
-            log_inputs[f"{ssl_phase}_{name_target}_{stage}/_input"] = \
-                lambda: batch[self.dataset.log_inputs[0]][0, 0, :3]
-            log_targets[f"{ssl_phase}_{name_target}_{stage}/_target"] = lambda t=name_target: batch[t][0, 0, 0]
-            log_preds[f"{ssl_phase}_{name_target}_{stage}/_pred"] = lambda t=name_target: engine.logits()[t][0, 0].argmax(dim=0)
+            log_inputs[f"{ssl_phase}_{name_target}_{stage}/_input"] = batch[self.dataset.log_inputs[0]][0, 0, :3]
+            log_targets[f"{ssl_phase}_{name_target}_{stage}/_target"] = batch[name_target][0, 0, 0]
+            log_preds[f"{ssl_phase}_{name_target}_{stage}/_pred"] = engine.logged_class_map(name_target)
         return log_inputs, log_preds, log_targets
 
     def probe_or_finetune_step(self, batch: dict, stage: str) -> dict:

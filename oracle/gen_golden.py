@@ -33,7 +33,9 @@ import torch  # noqa: E402
 
 REPO = Path(__file__).resolve().parent.parent
 REFERENCE = Path("/root/reference")
-GOLDEN = REPO / "tests" / "golden"
+import os  # noqa: E402
+
+GOLDEN = Path(os.environ.get("MAESTRO_GOLDEN_DIR", REPO / "tests" / "golden"))   # (tests redirect it to a temp directory)
 
 
 # ----------------------------------------------------------------------------- stubs
@@ -171,6 +173,13 @@ def case_table():
             dataset="treesatai_ts", ds_kwargs=dict(filter_targets=[]),
             mods=dict(aerial=dict(image_size=60, patch=20, bands=4, norm_bands=[1, 3], norm_fac=255.0)),
             size="tiny", model_kw=dict(depth=2), inter_depth=1, fusion="mod", B=2, seed=9),
+        # C5-shaped (S2-NAIP urban: aerial + spot + s2 + s1, four groups) with the SURVEY §8d "patch-group-wise norm stress"
+        # inputs: constant patches (sigma^2 -> 0 exercises the +1e-6 of model.py:226-229) and heavy-tailed exp(3 randn) bands
+        "c5_s2naip_stress": dict(
+            dataset="s2_naip", ds_kwargs=dict(),
+            mods=dict(aerial=dict(image_size=64, patch=16, bands=4, norm_bands=[1, 3], norm_fac=255.0),
+                      spot=dict(image_size=32, patch=16, bands=3, norm_fac=255.0)),
+            size="tiny", model_kw=dict(depth=3), inter_depth=1, fusion="group", B=2, seed=43, stress=True),   # (seed 41 has #struct-masked > k in one sample: tie-dependent)
     }
 
 
@@ -241,13 +250,28 @@ def build_datasets(case: dict, ns) -> object:
     return ns.DatasetsConfig(root_dir=None, name_dataset=case["dataset"], **{case["dataset"]: cls(**kw)})
 
 
-def make_batch(dataset, B: int, seed: int) -> dict:  # noqa: N803
+def stress_raster(x: torch.Tensor, patch: int, g: torch.Generator) -> torch.Tensor:
+    """SURVEY §8d norm-stress variant of a raster [B, D, C, S, S]: sample 0 gets per-patch CONSTANT tiles in its first
+    band (every norm group containing only that band has sigma^2 = 0 exactly), the last band of every sample is
+    heavy-tailed, exp(3 randn)."""
+    x = x.clone()
+    B, D, C, S, _ = x.shape  # noqa: N806
+    n = S // patch
+    const = torch.rand(D, n, n, generator=g)
+    x[0, :, 0] = const.repeat_interleave(patch, dim=1).repeat_interleave(patch, dim=2)
+    x[:, :, C - 1] = torch.exp(3.0 * torch.randn(B, D, S, S, generator=g))
+    return x
+
+
+def make_batch(dataset, B: int, seed: int, stress: bool = False) -> dict:  # noqa: N803
     """Synthetic batch of the wire format: rasters fp32 [B,D,C,S,S], dates int16 [B,D,3]."""
     batch = {}
     for i, (m, c) in enumerate(dataset.inputs.items()):
         g = torch.Generator().manual_seed(1234 + 97 * seed + i)
         C = c.bands if isinstance(c.bands, int) else sum(len(b) for b in c.bands)  # noqa: N806
         batch[m] = torch.rand(B, c.num_dates, C, c.image_size, c.image_size, generator=g)
+        if stress:
+            batch[m] = stress_raster(batch[m], c.patch_size.mae, g)
         d = torch.arange(c.num_dates)
         dates = torch.stack([torch.full_like(d, 2019), 100 + 7 * d + i, torch.full_like(d, 10)], dim=-1)
         batch[f"{m}_dates"] = dates[None].expand(B, -1, -1).clone().to(torch.int16)
@@ -329,7 +353,7 @@ def run_case(name: str, case: dict, ref, ours) -> dict:
     assert all(k.startswith("heads.") for k in missing), missing
     ssl.trainer = SimpleNamespace(ssl_phase="pretrain")
 
-    batch = make_batch(ds_our.dataset, case["B"], case["seed"])
+    batch = make_batch(ds_our.dataset, case["B"], case["seed"], stress=case.get("stress", False))
     out = {"weights_checksum": np.float64(chk)}
 
     # ---- reference forward/backward with recorded RNG draws
@@ -344,6 +368,11 @@ def run_case(name: str, case: dict, ref, ours) -> dict:
         ssl.loss_fn = torch.abs if loss.startswith("l1") else torch.square
         losses[loss] = ssl.compute_loss_rec(rb, rec, msk, stage="train")
         out[f"loss_{loss}"] = np.float64(losses[loss].item())
+    # image-log tensors of sample [0, 0] (model.py:160-193), as the reference's pretrain_step returns them every step
+    with torch.no_grad():
+        for logs in ssl.compute_logs_rec(rb, rec, msk, ssl_phase="pretrain", stage="train"):
+            for key, img in logs.items():
+                out[f"logs/{key}"] = img.detach().numpy().astype(np.float32)
     ssl.model.zero_grad()
     losses["l2_norm"].backward()
     grads = {k: p.grad for k, p in ssl.model.named_parameters() if p.grad is not None}
@@ -467,6 +496,84 @@ def run_sup_case(name: str, case: dict, ref, ours) -> dict:
     return out
 
 
+CKPT_CASE = dict(dataset="s2_naip", ds_kwargs=dict(filter_inputs=["spot"]),
+                 mods=dict(spot=dict(image_size=64, patch=8, bands=3, norm_fac=255.0)))
+CKPT_HP = dict(interpolate="nearest", fusion_mode="group", inter_depth=3, model="mae", model_size="tiny",
+               type_head="attentive", loss="l1_norm", use_date_enc=True, use_ema=True)
+CKPT_MASK = dict(mask_ratio=0.6, mask_loc=0.1)
+
+
+def ckpt_value(key: str, salt: int = 0) -> float:
+    """Constant fill value of checkpoint tensor ``key`` (low entropy on purpose: the gzip'ed fixture stays a few tens of KB
+    although the tiny model + its EMA copy hold 15 M parameters; what the fixture pins are keys, shapes, the pickled
+    hyper-parameters and that every tensor lands in its own slot)."""
+    import zlib
+    return (zlib.crc32(f"{salt}:{key}".encode()) % 251) / 256.0 - 0.5
+
+
+def _ref_namespace(ref):
+    return SimpleNamespace(
+        FLAIRConfig=ref.flair.FLAIRConfig, TreeSatAITSConfig=ref.ts.TreeSatAITSConfig,
+        PASTISHDConfig=ref.pastis.PASTISHDConfig, S2NAIPConfig=ref.s2.S2NAIPConfig,
+        InputRasterConfig=ref.InputRasterConfig, PatchSizeConfig=ref.PatchSizeConfig,
+        DatasetsConfig=lambda root_dir, name_dataset, **kw: ref.DatasetsConfig(
+            root_dir=root_dir, name_dataset=name_dataset,
+            **{k: kw.get(k, d()) for k, d in dict(
+                treesatai_ts=ref.ts.TreeSatAITSConfig, pastis_hd=ref.pastis.PASTISHDConfig,
+                flair=ref.flair.FLAIRConfig, s2_naip=ref.s2.S2NAIPConfig).items()}))
+
+
+def run_ckpt(ref, ours) -> None:
+    """Checkpoint interchange (``maestro/run_experiment.py:66-74``, ``maestro/train/model.py:118``).
+
+    (1) The REFERENCE ``SSLModule`` (tiny, ``use_ema=True``) is saved in Lightning's ``.ckpt`` layout with
+        ``hyper_parameters`` exactly as ``save_hyperparameters(ignore=["datasets"])`` records them -- ``mask`` is the
+        reference's own ``maestro.conf.mask.MaskConfig`` instance -> ``tests/golden/ref_written.ckpt.gz`` (data only).
+    (2) A checkpoint written by ``maestro_amd`` is loaded into the reference module with ``strict=True`` the way
+        ``LightningModule.load_from_checkpoint`` does it (``cls(**hyper_parameters, datasets=...)`` + ``load_state_dict``)."""
+    import gzip
+    import io
+    import tempfile
+
+    from maestro_amd.train.model import SSLModule as OurModule
+
+    ds_ref, ds_our = build_datasets(CKPT_CASE, _ref_namespace(ref)), build_datasets(CKPT_CASE, ours)
+    mask_ref = ref.MaskConfig(**CKPT_MASK)
+    ssl = ref.model.SSLModule(datasets=ds_ref, mask=mask_ref, **CKPT_HP)
+    with torch.no_grad():
+        for k, v in ssl.state_dict().items():
+            v.fill_(ckpt_value(k))
+    ckpt = {"epoch": 3, "global_step": 120, "pytorch-lightning_version": "2.5.0", "state_dict": ssl.state_dict(),
+            "loops": {}, "callbacks": {}, "optimizer_states": [], "lr_schedulers": [], "hparams_name": "kwargs",
+            "hyper_parameters": dict(mask=mask_ref, **CKPT_HP)}
+    buf = io.BytesIO()
+    torch.save(ckpt, buf)
+    with gzip.GzipFile(GOLDEN / "ref_written.ckpt.gz", "wb", compresslevel=9, mtime=0) as f:
+        f.write(buf.getvalue())
+    n_keys = len(ckpt["state_dict"])
+    print(f"[ckpt] reference-written checkpoint: {n_keys} tensors ({sum(k.startswith('ema_model.') for k in ckpt['state_dict'])} "
+          f"ema), {len(buf.getvalue()) / 1e6:.1f} MB raw -> {(GOLDEN / 'ref_written.ckpt.gz').stat().st_size / 1e3:.1f} KB gz")
+
+    # (2) ours -> reference
+    mod = OurModule(datasets=ds_our, mask=ours.MaskConfig(**CKPT_MASK), **CKPT_HP)
+    with torch.no_grad():
+        for k, v in mod.state_dict().items():
+            v.fill_(ckpt_value(k, salt=1))
+    with tempfile.TemporaryDirectory() as tmp:
+        path = Path(tmp) / "ours.ckpt"
+        mod.save_checkpoint(path)
+        back = torch.load(path, map_location="cpu", weights_only=False)     # the real maestro.conf.mask resolves here
+    assert type(back["hyper_parameters"]["mask"]) is ref.MaskConfig, type(back["hyper_parameters"]["mask"])
+    again = ref.model.SSLModule(datasets=ds_ref, **back["hyper_parameters"])
+    res = again.load_state_dict(back["state_dict"], strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in again.state_dict().items():
+        assert float(v.flatten()[0]) == np.float32(ckpt_value(k, salt=1)), k
+    assert again.model.mask_ratio and vars(back["hyper_parameters"]["mask"]) == vars(ours.MaskConfig(**CKPT_MASK))
+    print(f"[ckpt] maestro_amd-written checkpoint loaded into the reference SSLModule with strict=True "
+          f"({len(back['state_dict'])} tensors, mask = {back['hyper_parameters']['mask']})")
+
+
 def layer_vectors(ref) -> dict:
     """Known-answer vectors for the directly importable reference layers (embed.py / utils.py)."""
     out = {}
@@ -510,13 +617,17 @@ def main() -> None:
     ref = import_reference()
     GOLDEN.mkdir(parents=True, exist_ok=True)
     meta = dict(torch=torch.__version__, threads=torch.get_num_threads())
-    which = sys.argv[1] if len(sys.argv) > 1 else "all"      # all | pretrain | sup [case,case…]
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"      # all | pretrain | sup | ckpt  [case,case…]
+    only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None   # optional: comma-separated case names
     if which in ("all", "pretrain"):
         np.savez_compressed(GOLDEN / "layers.npz", **layer_vectors(ref))
         for name, case in case_table().items():
+            if only is not None and name not in only:
+                continue
             out = run_case(name, case, ref, ours)
             np.savez_compressed(GOLDEN / f"{name}.npz", torch_version=np.array(meta["torch"]), **out)
-    only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None   # optional: comma-separated case names
+    if which in ("all", "ckpt"):
+        run_ckpt(ref, ours)
     for name, case in (sup_case_table().items() if which in ("all", "sup") else ()):
         if only is not None and name not in only:
             continue

@@ -380,6 +380,23 @@ def compute_loss_rec(batch, pixels_rec, mask_rec, out_grid_size, norm_bands, los
     return total / wsum
 
 
+def compute_logs_rec(dataset, batch, pixels_rec, mask_rec, ssl_phase: str = "pretrain", stage: str = "train"):
+    """Image-log tensors of sample [0, 0] (reference ``maestro/train/model.py:160-193``): masked input (0 where masked, 1
+    where every channel is masked), reconstruction blended into the target, target -- ``batch`` is the RETURNED batch."""
+    log_inputs, log_preds, log_targets = {}, {}, {}
+    for name_mod in pixels_rec:
+        if name_mod not in dataset.log_inputs:
+            continue
+        msk, tgt = mask_rec[name_mod], batch[name_mod]
+        inputs = torch.where(msk, torch.zeros_like(tgt), tgt)
+        inputs = torch.where(torch.all(msk, dim=2, keepdim=True), torch.ones_like(tgt), inputs)
+        preds = torch.where(msk, pixels_rec[name_mod], tgt)
+        log_inputs[f"{ssl_phase}_{stage}/_{name_mod}_input"] = inputs[0, 0]
+        log_preds[f"{ssl_phase}_{stage}/_{name_mod}_rec"] = preds[0, 0]
+        log_targets[f"{ssl_phase}_{stage}/_{name_mod}_target"] = batch[name_mod][0, 0]
+    return log_inputs, log_preds, log_targets
+
+
 def oracle_step(model: OracleMAE, batch: dict, loss: str = "l2_norm", **fw):
     """forward + loss (+ keeps graph for backward); returns ``(loss, pixels_rec, mask_rec)``."""
     b = {k: (v.clone() if isinstance(v, Tensor) else copy.copy(v)) for k, v in batch.items()}

@@ -257,3 +257,44 @@ def test_param_store_notices_updates_made_outside_the_engine(monkeypatch):
     store.mark_synced()
     assert not store.refresh_half()
     assert store.fresh and store.grad_all.numel() == store.total + eng_mod.ALIGN and store.extra.numel() == eng_mod.ALIGN
+
+
+def test_reference_written_checkpoint_loads_without_the_reference(golden_dir, tmp_path):
+    """``tests/golden/ref_written.ckpt.gz`` was written by the REFERENCE ``SSLModule`` (tiny, ``use_ema=True``;
+    ``oracle/gen_golden.py ckpt``) in Lightning's layout -- its pickled hyper-parameters hold a
+    ``maestro.conf.mask.MaskConfig`` instance (``maestro/train/model.py:118``).  It must load here, where ``maestro`` is not
+    importable, strictly key for key including ``ema_model.*`` (``maestro/run_experiment.py:66-74``)."""
+    import gzip
+    import importlib.util
+    import zipfile
+
+    import maestro_amd.conf as conf
+    from maestro_amd.train.model import SSLModule
+    from oracle.gen_golden import CKPT_CASE, CKPT_HP, CKPT_MASK, build_datasets, ckpt_value
+
+    assert importlib.util.find_spec("maestro") is None, "this test must run without the reference on the path"
+    path = tmp_path / "ref.ckpt"
+    path.write_bytes(gzip.decompress((golden_dir / "ref_written.ckpt.gz").read_bytes()))
+    with zipfile.ZipFile(path) as z:
+        pkl = z.read(next(n for n in z.namelist() if n.endswith("data.pkl")))
+    assert b"maestro.conf.mask" in pkl and b"MaskConfig" in pkl       # the reference's own class path is in the pickle
+    ds = build_datasets(CKPT_CASE, conf)
+    mod = SSLModule.load_from_checkpoint(str(path), map_location="cpu", strict=True, datasets=ds)
+    assert mod.loaded_missing == [] and mod.loaded_unexpected == []
+    assert isinstance(mod._mask, conf.MaskConfig) and vars(mod._mask) == vars(conf.MaskConfig(**CKPT_MASK))
+    assert mod.loss_name == CKPT_HP["loss"] and mod.ema_model is not None and mod.model.inter_depth == CKPT_HP["inter_depth"]
+    sd = {k: v for k, v in mod.state_dict().items() if k != "_anchor"}
+    assert sum(k.startswith("ema_model.") for k in sd) == sum(k.startswith("model.") for k in sd) > 100
+    for k, v in sd.items():
+        assert float(v.flatten()[0]) == float(torch.tensor(ckpt_value(k), dtype=v.dtype)), k
+        assert float(v.min()) == float(v.max())
+    # the default call of run_experiment.py (strict=False) works as well, and so does dropping the EMA copy
+    assert SSLModule.load_from_checkpoint(str(path), strict=False, datasets=ds, use_ema=False).loaded_unexpected != []
+    # what this repo writes names the reference's class path only (nothing of maestro_amd is pickled)
+    out = tmp_path / "ours.ckpt"
+    mod.save_checkpoint(out)
+    with zipfile.ZipFile(out) as z:
+        pkl = z.read(next(n for n in z.namelist() if n.endswith("data.pkl")))
+    assert b"maestro.conf.mask" in pkl and b"maestro_amd" not in pkl
+    again = SSLModule.load_from_checkpoint(str(out), strict=True, datasets=ds)
+    assert all(torch.equal(a, b) for a, b in zip(again.state_dict().values(), mod.state_dict().values()))

@@ -72,7 +72,7 @@ def test_forward_loss_grads_match_reference(golden_dir, name):
     gold = _load(golden_dir, name)
     case, ds, oracle, chk = build_case(name)
     assert abs(chk - float(gold["weights_checksum"])) < 1e-6 * chk, "seeded weights differ from golden run"
-    batch = make_batch(ds.dataset, case["B"], case["seed"])
+    batch = make_batch(ds.dataset, case["B"], case["seed"], stress=case.get("stress", False))
     noise, struct = injected_rng(gold, oracle)
     tie_free = {k.split("/", 1)[1]: bool(gold[k]) for k in gold.files if k.startswith("tie_free/")}
     assert all(tie_free.values()), "golden cases are chosen tie-free for mask selection"
@@ -103,6 +103,14 @@ def test_forward_loss_grads_match_reference(golden_dir, name):
     b, rec, msk, _ = run(bool(multi_mod_groups))
     for m in rec:
         np.testing.assert_allclose(rec[m].detach().numpy(), gold[f"pixels_rec/{m}"], atol=5e-5)
+    # image logs of sample [0, 0] (model.py:160-193) against the tensors the reference's pretrain_step returned
+    logs = {}
+    for part in om.compute_logs_rec(ds.dataset, b, rec, msk):
+        logs.update(part)
+    stored = [k for k in gold.files if k.startswith("logs/")]
+    assert stored and {k.split("/", 1)[1] for k in stored} == set(logs)
+    for key in stored:
+        np.testing.assert_allclose(logs[key.split("/", 1)[1]].detach().numpy(), gold[key], atol=5e-5)
     nb = om.norm_bands_of(ds.dataset)
     for loss in ("l2_norm", "l1_norm", "l2", "l1"):
         val = om.compute_loss_rec(b, rec, msk, oracle.out_grid_size, nb, loss)

@@ -21,7 +21,7 @@ def build_sup_case(name):
                              inter_depth=case["inter_depth"], interpolate="nearest", model="mae", num_levels=1,
                              type_head=case["type_head"], fac_abs_enc=1.0, fac_date_enc=1.0, **case["model_kw"])
     chk = init_weights(oracle, case["seed"])
-    batch = make_batch(ds.dataset, case["B"], case["seed"])
+    batch = make_batch(ds.dataset, case["B"], case["seed"], stress=case.get("stress", False))
     batch.update(make_targets(ds.dataset, case["B"], case["seed"]))
     return case, ds, oracle, chk, batch
 
