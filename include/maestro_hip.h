@@ -184,6 +184,10 @@ int mh_gather_rows(const float* src, const int* idx, float* dst, int B, int src_
 /* Transpose of mh_gather_rows into a ZEROED dsrc (indices unique per sample -> plain stores). */
 int mh_scatter_rows(const float* ddst, const int* idx, float* dsrc, int B, int src_L, int n_idx, int dim, int dst_L,
                     int dst_off, void* stream);
+/* The same transpose written as a gather over every destination row: dst[b, t, :] = inv[b, t] >= 0 ? src[b, inv[b, t], :] : 0
+ * (inv = mh_mask_select's position map, -1 on masked tokens; src f32 [B, n, dim], dst f32 [B, L, dim]).  Backward of the
+ * visible-token gather x[batch, unmasked_indices] (mae.py:261) without a memset of the destination. */
+int mh_expand_rows(const float* src, const int* inv, float* dst, int B, int L, int n, int dim, void* stream);
 /* Decoder input assembly (mae.py:266-287 + mim.py:254-274):
  *   xdec[b,t,:] = (inv[b,t] < 0 ? mask_token[tok_slot[t]] : y[b, inv[b,t], :]) + pos[t,:] + date[b, date_row[t], :8 tail]
  * y f32 [B, n_vis, Dd]; mask_token f32 [slots, Dd]; pos f32 [L, Dd]; date f32 [B, n_date_rows, 8] or NULL. */

@@ -68,6 +68,22 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
     for (int c = lane * 4; c < dim; c += 256) *reinterpret_cast<f32x4*>(s + c) = *reinterpret_cast<const f32x4*>(d + c);
 }
 
+// dst[b, t, :] = inv[b, t] >= 0 ? src[b, inv[b, t], :] : 0 -- the scatter of the visible rows' gradient back to the full
+// sequence written as a gather over EVERY destination row, so the destination needs no memset in front of it
+__global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ src, const int* __restrict__ inv,
+                                                          float* __restrict__ dst, int B, int L, int n, int dim) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * L) return;
+    const int b = row / L, iv = inv[row];
+    float* o = dst + (size_t)row * dim;
+    const float* s = src + ((size_t)b * n + (iv < 0 ? 0 : iv)) * dim;
+    for (int c = lane * 4; c < dim; c += 256) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iv >= 0) v = *reinterpret_cast<const f32x4*>(s + c);
+        *reinterpret_cast<f32x4*>(o + c) = v;
+    }
+}
+
 // xdec[b,t,:] = (inv[b,t] < 0 ? mask_token[slot[t]] : y[b, inv[b,t], :]) + pos[t,:] + date8(b, date_row[t])
 __global__ __launch_bounds__(256) void unmask_kernel(const float* __restrict__ y, const int* __restrict__ inv,
                                                      const float* __restrict__ mask_token, const int* __restrict__ tok_slot,
@@ -169,6 +185,14 @@ extern "C" int mh_scatter_rows(const float* ddst, const int* idx, float* dsrc, i
     MH_CHECK_ARG(ddst && idx && dsrc && dim % 4 == 0 && dst_off + n_idx <= dst_L, "mh_scatter_rows: bad arguments");
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(ceil_div((long)B * n_idx, 4)), dim3(256), 0, (hipStream_t)stream, ddst, idx, dsrc,
                        B, src_L, n_idx, dim, dst_L, dst_off);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_expand_rows(const float* src, const int* inv, float* dst, int B, int L, int n, int dim, void* stream) {
+    MH_CHECK_ARG(src && inv && dst && B > 0 && L > 0 && n > 0 && dim % 4 == 0, "mh_expand_rows: bad arguments");
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(ceil_div((long)B * L, 4)), dim3(256), 0, (hipStream_t)stream, src, inv, dst, B, L,
+                       n, dim);
     MH_LAUNCH_CHECK();
     return 0;
 }

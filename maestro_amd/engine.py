@@ -974,9 +974,9 @@ class MAEEngine(EngineBase):
                 if not last:
                     return
                 dx0 = self._enc_state[g.name][0]
-                # scatter to the full group sequence (masked tokens get zero), then patch-embed backward per modality
-                gbuf["dxg"].zero_()
-                hip.scatter_rows(dx0, gbuf["vis"], gbuf["dxg"], g.Beff, g.L, g.N, E, g.N, 0)
+                # back to the full group sequence (masked tokens get zero: every row is written, no memset), then the
+                # patch-embed backward per modality
+                hip.expand_rows(dx0, gbuf["inv"], gbuf["dxg"], g.Beff, g.L, g.N, E)
                 for s in g.mods:
                     b = self.mb[s.name]
                     pe = b["pe"]

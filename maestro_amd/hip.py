@@ -282,6 +282,10 @@ def scatter_rows(ddst, idx, dsrc, B, src_L, n_idx, dim, dst_L, dst_off):
     call("mh_scatter_rows", ddst, idx, dsrc, _I(B), _I(src_L), _I(n_idx), _I(dim), _I(dst_L), _I(dst_off))
 
 
+def expand_rows(src, inv, dst, B, L, n, dim):
+    call("mh_expand_rows", src, inv, dst, _I(B), _I(L), _I(n), _I(dim))
+
+
 def unmask_assemble(y, inv, mask_token, tok_slot, pos, date, date_row, n_date_rows, xdec, B, L, n_vis, Dd):
     call("mh_unmask_assemble", y, inv, mask_token, tok_slot, pos, date, date_row, _I(n_date_rows), xdec, _I(B), _I(L),
          _I(n_vis), _I(Dd))

@@ -1,0 +1,128 @@
+"""Full-WIDTH parity: every BASELINE configuration (ViT-B C2 / C3 / C3' / C5 shapes, ViT-L C4) through the HIP engine AND
+through the fp32 CPU oracle (``oracle.mae.build_oracle``) with the same weights, the same synthetic inputs and the same
+injected host draws -- masks bit-exact, loss, reconstructions and EVERY parameter gradient.
+
+The oracle runs these at B = 1-2 in a few seconds each (bench.py's ``cpu_baseline`` times exactly this).  The golden cases of
+``tests/test_mae_gpu.py`` pin the same code against the REFERENCE at tiny width; this file carries the comparison to the real
+widths (E = 768 / 1024, 12 / 16 heads, 12 / 24 layers, 256-1024 tokens per group), reference presets
+``maestro/ssl/mae.py:345-378``.
+
+Tolerances (bf16 MFMA operands, fp32 accumulation, fp32 residual stream vs the fp32 oracle), <= 3x the errors observed on
+MI355X (``gpurun_out/observed_errors.jsonl`` of the round-2 runs; worst case over the five configurations in brackets):
+  mask indices ............ bit-exact
+  loss .................... |d| <= LOSS_TOL * |loss|
+  pixels_rec .............. relative L2 error <= PIX_TOL per modality
+  parameter gradients ..... relative L2 error <= GRAD_TOL per parameter (+ an absolute floor for ~zero gradients)
+"""
+
+import pytest
+import torch
+
+import bench
+import maestro_amd.conf as conf
+from maestro_amd.ssl import mae as pmae
+from oracle import mae as om
+from oracle.gen_golden import init_weights
+
+pytestmark = pytest.mark.gpu
+
+LOSS_TOL, PIX_TOL, GRAD_TOL = 3e-3, 2.5e-2, 5e-2
+COMMON = dict(interpolate="nearest", fusion_mode="group", inter_depth=3, model="mae", num_levels=1)
+
+
+def _rel(a, b):
+    return ((a - b).double().norm() / b.double().norm().clamp(min=1e-12)).item()
+
+
+@pytest.mark.parametrize("config,B", [("c3", 2), ("c2", 2), ("c3p", 1), ("c5", 2), ("c4", 1)])
+def test_engine_matches_oracle_at_full_width(config, B, observed):
+    from maestro_amd.train.trainer import synthetic_batch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    w = bench.WORKLOADS[config]
+    ds = w["ds"]()
+    torch.set_float32_matmul_precision("highest")
+    oracle = om.build_oracle(ds, conf.MaskConfig(), model_size=w["size"], **COMMON)
+    init_weights(oracle, 100 + len(config))
+    model = getattr(pmae, f"mae_{w['size']}")(datasets=ds, mask=conf.MaskConfig(), **COMMON)
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    batch = synthetic_batch(ds.dataset, B, "cpu", seed=3)
+    eng = model.engine(B, dev, loss="l2_norm")
+    torch.manual_seed(17)
+    noise, struct = eng.draw_masks()
+    loss = eng.forward({k: v.to(dev) for k, v in batch.items()}, noise=noise, struct=struct)
+    eng.zero_grad()
+    eng.backward()
+    torch.cuda.synchronize()
+    pixels, masks = eng.reconstructions()
+
+    ob, orec, omsk, _ = oracle({k: v.clone() for k, v in batch.items()}, "pretrain", noise=noise,
+                               struct_masks={g: s[:, :, None] for g, s in struct.items()})
+    oloss = om.compute_loss_rec(ob, orec, omsk, oracle.out_grid_size, om.norm_bands_of(ds.dataset), "l2_norm")
+    oracle.zero_grad()
+    oloss.backward()
+
+    tag = f"fullwidth/{config}"
+    for m in orec:
+        assert torch.equal(masks[m].cpu(), omsk[m]), f"{m}: mask differs from the oracle"
+        e = _rel(pixels[m].cpu(), orec[m].detach())
+        observed(tag, f"pixels/{m}", e)
+        assert e < PIX_TOL, (m, e)
+    e = abs(loss.item() - oloss.item()) / abs(oloss.item())
+    observed(tag, "loss", e)
+    assert e < LOSS_TOL, (loss.item(), oloss.item())
+    ograds = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
+    gmax = max(g.abs().max().item() for g in ograds.values())
+    worst, checked = (0.0, None), 0
+    for k, p in model.named_parameters():
+        if k not in ograds:
+            continue
+        got, want = eng.store.g(p).cpu(), ograds[k]
+        err, ref = (got - want).double().norm().item(), want.double().norm().item()
+        floor = 1e-5 * gmax * want.numel() ** 0.5
+        if ref > 10 * floor and err / ref > worst[0]:
+            worst = (err / ref, k)
+        assert err <= GRAD_TOL * ref + floor, f"{k}: grad rel err {err / max(ref, 1e-12):.3e} (|ref| = {ref:.3e})"
+        checked += 1
+    observed(tag, f"grad_worst/{worst[1]}", worst[0])
+    assert checked == len(ograds) and checked > 100
+    print(f"[{config}] loss hip={loss.item():.6f} oracle={oloss.item():.6f}; worst gradient rel L2 {worst}")
+
+
+def test_zero_masked_modality_gives_nan_like_the_reference(golden_dir):
+    """SURVEY Q8 (``maestro/train/model.py:241-243``): ``masked_select(...).mean()`` per modality is NaN when a modality of a
+    multi-modality group has no masked pixel in the whole batch.  The engine reproduces it (0 / 0 in ``mh_masked_loss``),
+    the oracle restates it.  Built with mask_ratio = 0.4 so that all masked tokens of the s1 group can sit in s1_asc."""
+    import numpy as np
+    from oracle.gen_golden import build_datasets, case_table, make_batch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    case = case_table()["c3p_dem_s1"]
+    ds = build_datasets(case, conf)
+    mask_cfg = conf.MaskConfig(mask_ratio=0.4)
+    kw = dict(interpolate="nearest", model="mae", num_levels=1, type_head="attentive", fac_abs_enc=1.0, fac_date_enc=1.0,
+              fusion_mode=case["fusion"], inter_depth=case["inter_depth"], **case["model_kw"])
+    oracle = om.build_oracle(ds, mask_cfg, model_size=case["size"], **kw)
+    init_weights(oracle, case["seed"])
+    model = getattr(pmae, f"mae_{case['size']}")(datasets=ds, mask=mask_cfg, **kw)
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    batch = make_batch(ds.dataset, case["B"], case["seed"])
+    eng = model.engine(case["B"], dev, loss="l2_norm")
+    torch.manual_seed(5)
+    noise, struct = eng.draw_masks()
+    struct = {g: torch.zeros_like(s) for g, s in struct.items()}
+    g1 = next(g for g in eng.groups if len(g.mods) > 1)
+    first, second = g1.mods[0], g1.mods[1]
+    assert g1.k <= first.n_tok, "all masked tokens must fit into the first modality of the group"
+    n = noise[g1.name]
+    n[:, first.tok_off: first.tok_off + first.n_tok] *= 0.4          # the k smallest draws all belong to the first modality
+    n[:, second.tok_off: second.tok_off + second.n_tok] = 0.5 + 0.5 * n[:, second.tok_off: second.tok_off + second.n_tok]
+    loss = eng.forward({k: v.to(dev) for k, v in batch.items()}, noise=noise, struct=struct)
+    _, masks = eng.reconstructions()
+    assert not masks[second.name].any() and masks[first.name].any()
+    ob, orec, omsk, _ = oracle({k: v.clone() for k, v in batch.items()}, "pretrain", noise=noise,
+                               struct_masks={g: s[:, :, None] for g, s in struct.items()})
+    oloss = om.compute_loss_rec(ob, orec, omsk, oracle.out_grid_size, om.norm_bands_of(ds.dataset), "l2_norm")
+    assert torch.isnan(oloss) and bool(np.isnan(loss.item())), (oloss.item(), loss.item())
