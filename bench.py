@@ -106,12 +106,46 @@ def build_model(workload: str, phase: str = "pretrain"):
 
 
 def host_cores() -> int:
-    """Threads for the CPU leg (every host core this process may run on, count stated in the line)."""
+    """Threads for the CPU leg (every host core this process may run on, count stated in the line): the
+    affinity mask, limited by the cgroup CPU quota when the box hands this job a share of a larger host (a 256-thread
+    pool on a 16-core share only thrashes: the round-2 box reported 256 schedulable CPUs and the leg timed out)."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / period + 0.5)))
+        except (OSError, ValueError, IndexError):
+            pass
     return max(1, n)
+
+
+def pick_cpu_threads(limit: int) -> tuple[int, dict]:
+    """Thread count for the CPU leg: the candidate (16, 32, 64, ..., all schedulable CPUs) with the highest measured fp32
+    GEMM rate on THIS host -- a box that exposes 256 CPUs but schedules the job on a 16-core share runs 15x slower with 256
+    threads than with 16 (the round-2 box timed the leg out), so "all cores" has to mean the cores that actually run."""
+    forced = os.environ.get("MAESTRO_CPU_THREADS")
+    if forced:
+        return max(1, min(limit, int(forced))), {}
+    cands = sorted({c for c in (8, 16, 32, 64, 128) if c < limit} | {limit})
+    a, b = torch.randn(1536, 1536), torch.randn(1536, 1536)
+    rates = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        a @ b
+        t0 = time.time()
+        for _ in range(4):
+            a @ b
+        rates[c] = round(4 * 2 * 1536 ** 3 / (time.time() - t0) / 1e9, 1)
+    best = max(rates, key=rates.get)
+    return best, rates
 
 
 def cpu_model() -> str:
@@ -132,9 +166,9 @@ def cpu_baseline_worker(workload: str, seconds: float, phase: str = "pretrain") 
 
     w = (WORKLOADS if phase == "pretrain" else SUP_WORKLOADS)[workload]
     ds = w["ds"]()
-    cores = host_cores()
-    torch.set_num_threads(cores)
     torch.set_float32_matmul_precision("highest")
+    cores, rates = pick_cpu_threads(host_cores())
+    torch.set_num_threads(cores)
     torch.manual_seed(42)
     model = om.build_oracle(ds, conf.MaskConfig(), model_size=w["size"], interpolate="nearest", fusion_mode="group",
                             inter_depth=3, model="mae", num_levels=1)
@@ -164,7 +198,7 @@ def cpu_baseline_worker(workload: str, seconds: float, phase: str = "pretrain") 
     return {"value": round(B / med, 4), "unit": "tiles/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "sample": f"{len(times)} timed steps (after {WARM} warm-ups) of the same {workload} {phase} workload at B={B}, fp32 "
                       f"('highest' matmul precision), torch CPU threads={cores}, forward+loss+backward+AdamW, median step "
-                      f"{med:.2f} s (min {times[0]:.2f} s)"}
+                      f"{med:.2f} s (min {times[0]:.2f} s); {host_cores()} schedulable CPUs, fp32 GEMM GFLOP/s by thread count {rates}"}
 
 
 def cpu_baseline(workload: str, seconds: float, phase: str = "pretrain") -> dict:
@@ -174,7 +208,7 @@ def cpu_baseline(workload: str, seconds: float, phase: str = "pretrain") -> dict
     cap = 8 * seconds + 90
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", workload, "--cpu-seconds", str(seconds),
            "--phase", phase]
-    env = dict(os.environ, OMP_NUM_THREADS=str(host_cores()), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=cap, env=env)
         for line in reversed(r.stdout.strip().splitlines()):

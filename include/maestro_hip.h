@@ -80,6 +80,30 @@ typedef struct MhGroupedGemm {
 int mh_gemm_grouped_tn(const MhGroupedGemm* table_device, int n_problems, const uint32_t* tile_queues, int queue_len,
                        void* stream);
 
+/* Grouped forward / dgrad GEMM: ONE persistent launch (one 512-thread workgroup per CU) over the tiles of several
+ * independent problems of one layout (MH_GEMM_NT or MH_GEMM_NN, argument meaning and epilogue flags as mh_gemm_bf16;
+ * no MH_GEMM_ATOMIC), e.g. the same layer-op of every modality group's encoder / decoder (the per-group Transformers of
+ * maestro/ssl/mae.py:135-174 run identical ops on different token rows).  K %% 32 == 0, K >= 64, N %% 8 == 0.
+ *   problems: DEVICE array; a_bytes / b_bytes = operand extents in bytes ((M-1) lda + K) * 2 etc. -- the buffer descriptors
+ *             make rows beyond M / N read as zero; mh_gemm_grouped_check validates a HOST copy of the table.
+ *   items:    DEVICE array of n_items work items, two uint32 each: { problem | MH_GTILE_* << 16, (m0 / 64) | (n0 / 64) << 16 }.
+ *             Worker w (of n_workers, a multiple of 8, normally the CU count) runs items w', w' + n_workers, ... in order
+ *             (w' = (w %% 8) * n_workers / 8 + w / 8: workers on one XCD take neighbouring items); consecutive items of one
+ *             shape keep the LDS-DMA pipeline filled across the tile boundary.  The item list must cover every output
+ *             element of every problem exactly once (shapes may be mixed freely: the host balances the workers with
+ *             half / quarter tiles instead of split-K).  MH_GTILE_128 is not valid for MH_GEMM_COLSUM problems. */
+enum { MH_GTILE_256 = 0, MH_GTILE_128x256 = 1, MH_GTILE_256x128 = 2, MH_GTILE_128 = 3 };   /* rows x cols */
+typedef struct MhGemmProblem {
+    const void* A; const void* B; void* C;
+    const float* bias; const float* res; const void* aux_in; void* aux_out; float* colsum;
+    int M, N, K, lda, ldb, ldc, ldr, ldaux, flags;
+    unsigned a_bytes, b_bytes;
+    int reserved;
+} MhGemmProblem;
+int mh_gemm_grouped_check(int layout, const MhGemmProblem* problems_host, int n_problems);
+int mh_gemm_grouped(int layout, const MhGemmProblem* problems_device, int n_problems, const uint32_t* items_device,
+                    int n_items, int n_workers, void* stream);
+
 /* ---------------------------------------------------------------------------------------------- LayerNorm
  * y = (x - mean) * rstd * gamma + beta over the last dim; x f32 (residual stream), y bf16 (GEMM operand) or f32.
  * Rows are addressed as row(b, j) = b * L + off + j (j < n) on both sides, so the split / concat of group sequences

@@ -24,9 +24,11 @@ int gemm_dma_dispatch(int tile, int layout, int M, int N, int K, const void* A, 
 // GELU' / aux): each wave transposes its tile through a private LDS region (passes of 32 rows, 68-float row pitch:
 // conflict-free ds_write_b128 / ds_read_b128) so that the aux reads and the C / aux writes are done in ROW-MAJOR lane
 // order: 8 lanes cover one 128-byte row segment with 16-byte accesses.
-template <int MT>
+template <int MT, int RP = 32>   // RP = rows per staging pass (32: 32 x 68 floats per wave; 16: half of that)
 __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f32x4 (&acc)[4][MT], float* st, int m_base,
                                                     int n_base) {
+    constexpr int TPP = RP / 16, NPASS = MT / TPP, SUB = RP / 8;   // m-tiles per pass, passes, 8-row groups per pass
+    static_assert((RP == 16 || RP == 32) && MT % TPP == 0, "staging pass geometry");
     const int l = threadIdx.x & 63, g = l >> 4, lm = l & 15;
     const bool out_f32 = p.flags & MH_GEMM_OUT_F32;
     if (out_f32) {
@@ -56,12 +58,12 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
     }
     f32x4 cs_lo = {0, 0, 0, 0}, cs_hi = {0, 0, 0, 0};   // MH_GEMM_COLSUM: this lane's 8 columns summed over its rows
 #pragma unroll
-    for (int pass_m = 0; pass_m < MT / 2; ++pass_m) {
+    for (int pass_m = 0; pass_m < NPASS; ++pass_m) {
 #pragma unroll
-        for (int i = 2 * pass_m; i < 2 * pass_m + 2; ++i)
+        for (int i = TPP * pass_m; i < TPP * pass_m + TPP; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<f32x4*>(st + (16 * (i - 2 * pass_m) + lm) * 68 + 16 * j + 4 * g) = acc[j][i];
+                *reinterpret_cast<f32x4*>(st + (16 * (i - TPP * pass_m) + lm) * 68 + 16 * j + 4 * g) = acc[j][i];
         {
             const int c = (l & 7) * 8, n = n_base + c;
             f32x4 b_lo = {0, 0, 0, 0}, b_hi = {0, 0, 0, 0};
@@ -69,18 +71,18 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                 b_lo = *reinterpret_cast<const f32x4*>(p.bias + n);
                 b_hi = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
             }
-            u32x4 aux_pre[4];
+            u32x4 aux_pre[SUB];
             if (p.flags & (MH_GEMM_DGELU | MH_GEMM_MULAUX)) {
 #pragma unroll
-                for (int pass = 0; pass < 4; ++pass) {
-                    const int m = m_base + 32 * pass_m + pass * 8 + (l >> 3);
+                for (int pass = 0; pass < SUB; ++pass) {
+                    const int m = m_base + RP * pass_m + pass * 8 + (l >> 3);
                     aux_pre[pass] = (u32x4){0, 0, 0, 0};
                     if (m < p.M && n < p.N) aux_pre[pass] = *reinterpret_cast<const u32x4*>(p.aux_in + (size_t)m * p.ldaux + n);
                 }
             }
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int r = pass * 8 + (l >> 3), m = m_base + 32 * pass_m + r;
+            for (int pass = 0; pass < SUB; ++pass) {
+                const int r = pass * 8 + (l >> 3), m = m_base + RP * pass_m + r;
                 f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * 68 + c);
                 f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * 68 + c + 4);
                 if (m < p.M && n < p.N) {
@@ -119,7 +121,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                     *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
                 }
             }
-            if ((p.flags & MH_GEMM_COLSUM) && (pass_m & 1)) {
+            if ((p.flags & MH_GEMM_COLSUM) && (RP * (pass_m + 1)) % 64 == 0) {
                 // one 64-row block done: lanes with equal (l & 7) hold the same 8 columns -> fold the 8 row groups and
                 // store the block's partial column sums as row (m / 64) of the [ceil(M / 64), N] workspace (no atomics)
 #pragma unroll
@@ -130,7 +132,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                         cs_hi[e] += __shfl_xor(cs_hi[e], o, 64);
                     }
                 }
-                const int m_blk = m_base + 32 * (pass_m - 1);
+                const int m_blk = m_base + RP * (pass_m + 1) - 64;
                 if (l < 8 && n < p.N && m_blk < p.M) {
                     float* dst = p.colsum + (size_t)(m_blk >> 6) * p.N + n;
                     *reinterpret_cast<f32x4*>(dst) = cs_lo;

@@ -48,6 +48,9 @@ __global__ __launch_bounds__(256) void masked_loss_kernel(const float* __restric
     if (threadIdx.x == 0) {
         const float t = (red[0] + red[1]) + (red[2] + red[3]);
         if (t != 0.f) atomicAdd(acc, t * coef);  // coef = weight / n_elems -> acc accumulates the weighted loss
+        // a modality without a single masked token in the batch: the reference takes the mean of an empty selection
+        // (maestro/train/model.py:241-243) -> NaN loss, zero gradient for this modality; reproduced, not guarded
+        if (blockIdx.x == 0 && *n_masked == 0) atomicAdd(acc, __builtin_nanf(""));
     }
 }
 

@@ -26,7 +26,7 @@ from oracle.gen_golden import init_weights
 
 pytestmark = pytest.mark.gpu
 
-LOSS_TOL, PIX_TOL, GRAD_TOL = 3e-3, 2.5e-2, 5e-2
+LOSS_TOL, PIX_TOL, GRAD_TOL = 1e-3, 2e-2, 4.5e-2   # observed worst: 3.5e-4 (C4), 6.9e-3 (C3' s1_asc), 1.53e-2 (C5)
 COMMON = dict(interpolate="nearest", fusion_mode="group", inter_depth=3, model="mae", num_levels=1)
 
 
@@ -126,3 +126,7 @@ def test_zero_masked_modality_gives_nan_like_the_reference(golden_dir):
                                struct_masks={g: s[:, :, None] for g, s in struct.items()})
     oloss = om.compute_loss_rec(ob, orec, omsk, oracle.out_grid_size, om.norm_bands_of(ds.dataset), "l2_norm")
     assert torch.isnan(oloss) and bool(np.isnan(loss.item())), (oloss.item(), loss.item())
+    eng.zero_grad()
+    eng.backward()           # ... while the gradients stay finite (an empty selection back-propagates zeros)
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.store.grad).all() and float(eng.store.grad.abs().sum()) > 0
