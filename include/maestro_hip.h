@@ -104,6 +104,35 @@ int mh_gemm_grouped_check(int layout, const MhGemmProblem* problems_host, int n_
 int mh_gemm_grouped(int layout, const MhGemmProblem* problems_device, int n_problems, const uint32_t* items_device,
                     int n_items, int n_workers, void* stream);
 
+/* fp8 GEMM (BASELINE configs[4], "ViT-Base MAE fp8 MFMA path"): C[M, N] = (*descale_a) (*descale_b) A8[M, K] B8[N, K]^T
+ * with the epilogues of mh_gemm_bf16 (flags, bias, res, aux_in / aux_out, colsum: same meaning; no MH_GEMM_ATOMIC).  Both
+ * operands are K-minor bytes: B8 = a weight [N, K] in OCP e4m3 (the forward uses the weight as stored, the dgrad its
+ * transposed fp8 shadow), A8 = activations in e4m3 or gradients in e5m2 (a_format).  K %% 128 == 0, lda / ldb %% 16 == 0 (bytes).
+ * descale_a / descale_b: DEVICE scalars 1 / scale of the per-tensor quantisers below (mh_quant_batched).  Optional c8
+ * (bf16-output epilogues only): an e4m3 copy of the output times *c8_scale (the next fp8 GEMM's A operand: fc1 -> fc2),
+ * with max |output| folded into *c8_amax (delayed scaling).  Replaces the nn.Linear calls inside vit_pytorch's Attention /
+ * FeedForward (call sites maestro/ssl/mae.py:135-174) when the step runs with fp8 operands. */
+enum { MH_FP8_E4M3 = 0, MH_FP8_E5M2 = 1 };
+int mh_gemm_fp8(int M, int N, int K, const void* A8, int lda, int a_format, const void* B8, int ldb, void* C, int ldc,
+                int flags, const float* descale_a, const float* descale_b, const float* bias, const float* res, int ldr,
+                const void* aux_in, void* aux_out, int ldaux, float* colsum, void* c8, int ldc8, const float* c8_scale,
+                float* c8_amax, void* stream);
+/* Per-tensor fp8 quantisation, batched over a job table (DEVICE array): job = one tensor of n elements (n %% 4 == 0), f32 or
+ * bf16 source, `slot` = its entry in the scale / amax tables.  items: DEVICE array of work items job << 32 | chunk (chunks of
+ * 4096 elements).  mode 0: amax[slot] = max(amax[slot], max |src|) only;  1: dst = fp8(src * scale[slot]) (+ the transposed
+ * copy dst_t [cols, rows] of a [rows, cols] tensor when dst_t != NULL, cols %% 4 == 0);  2: cast AND fold max |src| into amax
+ * (delayed scaling of activations: this step casts with the previous step's scale).  Values saturate at the format's largest
+ * finite number.  mh_fp8_update_scales: scale = 2^(floor(log2(format_max / amax)) - margin_log2) (1 while amax is 0),
+ * descale = 1 / scale, amax reset to 0 -- all on the device, capturable. */
+typedef struct MhQuantJob {
+    const void* src; void* dst; void* dst_t;
+    long n;
+    int rows, cols, slot, is_f32, format, reserved;
+} MhQuantJob;
+int mh_quant_batched(const MhQuantJob* jobs_device, const unsigned long* items_device, int n_items, const float* scale,
+                     float* amax, int mode, void* stream);
+int mh_fp8_update_scales(float* amax, float* scale, float* descale, int n, float format_max, int margin_log2, void* stream);
+
 /* ---------------------------------------------------------------------------------------------- LayerNorm
  * y = (x - mean) * rstd * gamma + beta over the last dim; x f32 (residual stream), y bf16 (GEMM operand) or f32.
  * Rows are addressed as row(b, j) = b * L + off + j (j < n) on both sides, so the split / concat of group sequences

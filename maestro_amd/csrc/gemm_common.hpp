@@ -12,7 +12,29 @@ struct GemmParams {
     int tiles_m, tiles_n, k_per_split;
     int fast;               // 1: buffer-load path (no K tail inside a K-minor operand, extents < 2 GiB)
     unsigned a_bytes, b_bytes;
+    // fp8 path (gemm_fp8.hip; null / 0 for the bf16 kernels): the accumulators are multiplied by *descale_a x *descale_b (the
+    // per-tensor dequantisation factors, device scalars) before the epilogue; c8 (optional, bf16-output epilogues): an OCP
+    // e4m3 copy of the output scaled by *c8_scale, the operand of the next fp8 GEMM, with max |value| folded into *c8_amax
+    const float* descale_a = nullptr; const float* descale_b = nullptr;
+    uint8_t* c8 = nullptr; const float* c8_scale = nullptr; float* c8_amax = nullptr; int ldc8 = 0;
 };
+
+// 8 floats -> 8 OCP e4m3 bytes (saturating at +-448: e4m3fn has no infinity, an overflow would become NaN)
+__device__ __forceinline__ u32x2 pack_fp8x8(f32x4 lo, f32x4 hi, float s) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        lo[e] = fminf(fmaxf(lo[e] * s, -448.f), 448.f);
+        hi[e] = fminf(fmaxf(hi[e] * s, -448.f), 448.f);
+    }
+    int a = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], 0, false);
+    a = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], a, true);
+    int b = __builtin_amdgcn_cvt_pk_fp8_f32(hi[0], hi[1], 0, false);
+    b = __builtin_amdgcn_cvt_pk_fp8_f32(hi[2], hi[3], b, true);
+    return (u32x2){(uint32_t)a, (uint32_t)b};
+}
+__device__ __forceinline__ void atomic_max_pos(float* dst, float v) {   // v >= 0: the int order of the bits is the float order
+    atomicMax(reinterpret_cast<int*>(dst), __float_as_int(v));
+}
 
 // gemm_dma.hip: the LDS-DMA tile family (tile = MH_TILE_DMA_*); -2 = not eligible, nothing launched
 int gemm_dma_dispatch(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
@@ -31,6 +53,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
     static_assert((RP == 16 || RP == 32) && MT % TPP == 0, "staging pass geometry");
     const int l = threadIdx.x & 63, g = l >> 4, lm = l & 15;
     const bool out_f32 = p.flags & MH_GEMM_OUT_F32;
+    const float alpha = p.descale_a ? *p.descale_a * *p.descale_b : 1.f;   // fp8 operands: per-tensor dequantisation
     if (out_f32) {
         // fp32 output straight from the accumulators: lane (lm, g) owns 4 consecutive columns of row 16i + lm in every
         // n-tile, i.e. 16-byte accesses that four lanes extend to a 64-byte row segment; no LDS round trip.
@@ -51,12 +74,14 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
             for (int j = 0; j < 4; ++j) {
                 const int n = n_base + 16 * j + 4 * g;
                 if (m < p.M && n < p.N)
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = acc[j][i] + add[j];
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = acc[j][i] * alpha + add[j];
             }
         }
         return;
     }
     f32x4 cs_lo = {0, 0, 0, 0}, cs_hi = {0, 0, 0, 0};   // MH_GEMM_COLSUM: this lane's 8 columns summed over its rows
+    const float s8 = p.c8 ? *p.c8_scale : 0.f;
+    float amax8 = 0.f;
 #pragma unroll
     for (int pass_m = 0; pass_m < NPASS; ++pass_m) {
 #pragma unroll
@@ -86,7 +111,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                 f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * 68 + c);
                 f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * 68 + c + 4);
                 if (m < p.M && n < p.N) {
-                    lo += b_lo; hi += b_hi;
+                    lo = lo * alpha + b_lo; hi = hi * alpha + b_hi;
                     if (p.flags & MH_GEMM_GELU) {
                         f32x4 c_lo, d_lo, c_hi, d_hi;      // CDF and PDF of the pre-activation (one exp2 + one rcp per element)
                         gelu_cdf_pdf4(lo, c_lo, d_lo);
@@ -119,6 +144,11 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                     cs_lo += lo; cs_hi += hi;
                     u32x4 pk = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
                     *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
+                    if (p.c8) {
+                        *reinterpret_cast<u32x2*>(p.c8 + (size_t)m * p.ldc8 + n) = pack_fp8x8(lo, hi, s8);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) amax8 = fmaxf(amax8, fmaxf(fabsf(lo[e]), fabsf(hi[e])));
+                    }
                 }
             }
             if ((p.flags & MH_GEMM_COLSUM) && (RP * (pass_m + 1)) % 64 == 0) {
@@ -141,6 +171,10 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                 cs_lo = (f32x4){0, 0, 0, 0}; cs_hi = (f32x4){0, 0, 0, 0};
             }
         }
+    }
+    if (p.c8 && p.c8_amax) {
+        amax8 = wave_max(amax8);
+        if (l == 0 && amax8 > 0.f) atomic_max_pos(p.c8_amax, amax8);
     }
 }
 

@@ -15,12 +15,15 @@
 //          fragments by ds_read_b64_tr_b16 (hardware transpose)
 // Out-of-range rows / K rows read as zero through the buffer descriptor's extent (no predication anywhere).
 #include "gemm_ring.hpp"
+#include <stdlib.h>
 
 namespace {
 
 // (CALLER only makes the instantiations of the two kernels distinct: the host pass of hipcc 7.2 rejects the second request
 // for one and the same specialization with a bogus "substitution failure".)
-template <class T, bool A_KMAJOR, bool B_KMAJOR, int CALLER>
+// STAGGER (8-wave tile only): waves 4-7 run half a K step behind waves 0-3 (see the main loop).  MH_DMA_STAGGER=0 in the
+// environment selects the lockstep instantiation at run time (A/B measurements: scripts/bench_tiles.py).
+template <class T, bool A_KMAJOR, bool B_KMAJOR, int CALLER, bool STAGGER>
 __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, int tile_n, int kbeg, int kend,
                                               unsigned char* smem) {
     constexpr int S = T::S, PA = T::PA, PB = T::PB, NW = T::NW;
@@ -62,16 +65,17 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
 
     for (int t = 0; t < S - 1 && t < nk; ++t) issue(t);
 
-    for (int t = 0; t < nk; ++t) {
-        // my pieces of step t have landed once at most the S - 2 younger steps' DMA instructions are still pending
-        const int younger = min(S - 2, nk - 1 - t);
+    // my pieces of step `step` have landed once at most the S - 2 younger steps' DMA instructions are still pending
+    auto wait_step = [&](int step) {
+        const int younger = min(S - 2, nk - 1 - step);
         if (younger >= 2) wait_vmcnt<2 * (PA + PB)>();
         else if (younger == 1) wait_vmcnt<PA + PB>();
         else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();   // everybody's pieces of step t are in LDS; step t-1 has been read by everybody
+    };
+    bf16x8 fa[MT], fb[4];
+    auto load_step = [&](int t) {
         const unsigned char* ta = smem + (t % S) * T::STAGE_BYTES;
         const unsigned char* tb = ta + T::A_BYTES;
-        bf16x8 fa[MT], fb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR, T::BN>(tb, wn + 16 * j);
 #pragma unroll
@@ -79,25 +83,74 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
         // Order matters: (1) all 24 fragment reads of the K step go out first (left alone, the scheduler interleaves them two
         // fragments at a time to save registers and every group of 4 MFMAs then waits on LDS: +2 %); (2) only then the DMA
         // pieces that refill the slot step t-1 vacated -- an LDS-DMA instruction costs the wave ~100 issue cycles, and issued
-        // in front of the reads (as this kernel first did) it held the whole step back: grouped wgrad 754 -> 1050 TFLOP/s;
-        // (3) the MFMAs, whose operands arrive while the DMA instructions issue.
+        // in front of the reads (as this kernel first did) it held the whole step back: grouped wgrad 754 -> 1050 TFLOP/s.
         __builtin_amdgcn_sched_barrier(0);
         if (t + S - 1 < nk) issue(t + S - 1);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    auto math_step = [&]() {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+    };
+
+    if constexpr (NW == 8 && STAGGER) {
+        // Two waves share every SIMD (w and w + 4).  Run in lockstep they both read / issue DMA (no MFMA on the SIMD for
+        // ~500 cycles) and then both compute (the matrix pipe serialises their MFMAs): measured 1125 ns per K step against
+        // 657 ns for the MFMAs alone and 652 ns for the DMA stream alone (scripts/bench_persist_ablate.py).  Here waves 4-7
+        // run HALF A STEP behind waves 0-3 -- two barriers per K step, each wave alternates a load phase (fragment reads +
+        // DMA issue) and a math phase (32 MFMAs) -- so one partner's MFMAs cover the other's reads and DMA issue:
+        //     phase 2t   : waves 0-3 load step t      | waves 4-7 compute step t-1
+        //     phase 2t+1 : waves 0-3 compute step t   | waves 4-7 load step t      ; everyone waits for ITS pieces of step t+1
+        // Pieces of step t+1 are first read in phase 2t+2, behind the barrier that follows those waits; the slot refilled in
+        // a load phase of step t (step t+S-1 -> slot of step t-1) was last read in phase 2t-1.  Same K order per output
+        // element as the lockstep loop: bit-identical results.
+        wait_step(0);
+        __builtin_amdgcn_s_barrier();
+        if (w < 4) {                   // wave-uniform role; both roles execute 2 nk barriers
+            for (int t = 0; t < nk; ++t) {
+                load_step(t);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1); math_step(); __builtin_amdgcn_s_setprio(0);
+                if (t + 1 < nk) wait_step(t + 1);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            __builtin_amdgcn_s_barrier();          // phase 0: nothing to compute yet
+            __builtin_amdgcn_sched_barrier(0);
+            for (int t = 0; t < nk; ++t) {
+                load_step(t);                      // phase 2t+1
+                if (t + 1 < nk) wait_step(t + 1);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1); math_step(); __builtin_amdgcn_s_setprio(0);   // phase 2t+2
+                if (t + 1 < nk) {
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // (the last math phase touches no LDS: the ring is free for the epilogue staging of the early waves)
+        }
+    } else {
+        for (int t = 0; t < nk; ++t) {
+            wait_step(t);
+            __builtin_amdgcn_s_barrier();   // everybody's pieces of step t are in LDS; step t-1 has been read by everybody
+            load_step(t);
+            math_step();                    // (3) the MFMAs, whose operands arrive while the DMA instructions issue
+        }
+        __builtin_amdgcn_s_barrier();   // all reads of the ring are done: reuse it as epilogue staging
     }
-    __builtin_amdgcn_s_barrier();   // all reads of the ring are done: reuse it as epilogue staging
 
     float* st = reinterpret_cast<float*>(smem) + w * (32 * 68);
     if (p.flags & MH_GEMM_ATOMIC) gemm_epilogue_atomic<MT>(p, acc, st, m0 + wm, n0 + wn);
     else gemm_epilogue_store<MT>(p, acc, st, m0 + wm, n0 + wn);
 }
 
-template <class T, bool A_KMAJOR, bool B_KMAJOR>
+template <class T, bool A_KMAJOR, bool B_KMAJOR, bool STAGGER>
 // Second launch bound = workgroups per CU: without it the 128- and 256-thread tiles were given 304 VGPRs, i.e. ONE wave per
 // SIMD and one workgroup per CU instead of the two (four) their LDS footprint was sized for.
 __global__ __launch_bounds__(T::NT, T::MIN_WG) void gemm_dma_kernel(GemmParams p) {
@@ -111,7 +164,7 @@ __global__ __launch_bounds__(T::NT, T::MIN_WG) void gemm_dma_kernel(GemmParams p
     const int gsz = min(p.tiles_m - first_m, GROUP_M);
     const int tile_m = first_m + in_group % gsz, tile_n = in_group / gsz;
     const int kbeg = blockIdx.y * p.k_per_split;
-    gemm_dma_tile<T, A_KMAJOR, B_KMAJOR, 0>(p, tile_m, tile_n, kbeg, min(p.K, kbeg + p.k_per_split), smem);
+    gemm_dma_tile<T, A_KMAJOR, B_KMAJOR, 0, STAGGER>(p, tile_m, tile_n, kbeg, min(p.K, kbeg + p.k_per_split), smem);
 }
 
 typedef Tile<2, 4, 4> T256;      // 256 x 256
@@ -124,7 +177,7 @@ typedef Tile<2, 2, 4, 4> T128q;  // 128 x 128, four 64 x 64 waves
 // (dW_i[M_i, N_i] = dY_i^T X_i, K_i = tokens), no split-K.  Workgroup b (placed on XCD b % 8 by the hardware) runs entry
 // b / 8 of that XCD's host-built tile queue, so that the tiles of one problem run side by side under one L2 and sweep
 // K together: a dY / X panel is then fetched from HBM once per problem instead of once per tile.
-template <class T>
+template <class T, bool STAGGER>
 __global__ __launch_bounds__(T::NT) void gemm_dma_grouped_tn_kernel(const MhGroupedGemm* __restrict__ table, int n_problems,
                                                                     const uint32_t* __restrict__ queues, int queue_len) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[T::LDS_BYTES];
@@ -141,7 +194,12 @@ __global__ __launch_bounds__(T::NT) void gemm_dma_grouped_tn_kernel(const MhGrou
     p.b_bytes = (unsigned)(((long)(g.K - 1) * g.ldb + g.N) * 2);
     const int tile_m = (e >> 8) & 0xff, tile_n = e & 0xff;
     if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
-    gemm_dma_tile<T, true, true, 1>(p, tile_m, tile_n, 0, g.K, smem);
+    gemm_dma_tile<T, true, true, 1, STAGGER>(p, tile_m, tile_n, 0, g.K, smem);
+}
+
+static bool stagger_on() {
+    const char* e = getenv("MH_DMA_STAGGER");
+    return !(e && e[0] == '0');
 }
 
 template <class T>
@@ -162,10 +220,18 @@ int launch_dma(int layout, GemmParams& p, hipStream_t s) {
     p.k_per_split = ksteps_per * BK;
     splits = ceil_div(K, p.k_per_split);
     dim3 grid(p.tiles_m * p.tiles_n, splits), block(T::NT);
+    if (T::NW == 8 && stagger_on()) {
+        switch (layout) {
+            case 0: hipLaunchKernelGGL((gemm_dma_kernel<T, false, false, T::NW == 8>), grid, block, 0, s, p); break;
+            case 1: hipLaunchKernelGGL((gemm_dma_kernel<T, false, true, T::NW == 8>), grid, block, 0, s, p); break;
+            default: hipLaunchKernelGGL((gemm_dma_kernel<T, true, true, T::NW == 8>), grid, block, 0, s, p); break;
+        }
+        return 0;
+    }
     switch (layout) {
-        case 0: hipLaunchKernelGGL((gemm_dma_kernel<T, false, false>), grid, block, 0, s, p); break;
-        case 1: hipLaunchKernelGGL((gemm_dma_kernel<T, false, true>), grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm_dma_kernel<T, true, true>), grid, block, 0, s, p); break;
+        case 0: hipLaunchKernelGGL((gemm_dma_kernel<T, false, false, false>), grid, block, 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm_dma_kernel<T, false, true, false>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_dma_kernel<T, true, true, false>), grid, block, 0, s, p); break;
     }
     return 0;
 }
@@ -176,8 +242,12 @@ extern "C" int mh_gemm_grouped_tn(const MhGroupedGemm* table_device, int n_probl
                                   int queue_len, void* stream) {
     MH_CHECK_ARG(table_device && tile_queues && n_problems > 0 && n_problems < 65536 && queue_len > 0,
                  "mh_gemm_grouped_tn: bad arguments");
-    hipLaunchKernelGGL(gemm_dma_grouped_tn_kernel<T256>, dim3(8 * queue_len), dim3(T256::NT), 0, (hipStream_t)stream,
-                       table_device, n_problems, tile_queues, queue_len);
+    if (stagger_on())
+        hipLaunchKernelGGL((gemm_dma_grouped_tn_kernel<T256, true>), dim3(8 * queue_len), dim3(T256::NT), 0, (hipStream_t)stream,
+                           table_device, n_problems, tile_queues, queue_len);
+    else
+        hipLaunchKernelGGL((gemm_dma_grouped_tn_kernel<T256, false>), dim3(8 * queue_len), dim3(T256::NT), 0, (hipStream_t)stream,
+                           table_device, n_problems, tile_queues, queue_len);
     MH_LAUNCH_CHECK();
     return 0;
 }

@@ -70,7 +70,9 @@ __device__ __forceinline__ int ring_next(int s) { return s + 1 == PS ? 0 : s + 1
 
 // One run of consecutive work-list items of tile shape T for this worker.  On return `i` / `item` name the worker's next
 // item (of another shape) or `i >= n_items`.
-template <class T, bool B_KMAJOR>
+// ABL (diagnostic builds only, scripts/bench_persist_ablate.py): 0 = the kernel; 1 = DMA stream only (no fragment reads, no
+// MFMAs); 2 = fragment reads + MFMAs only (no DMA: stale LDS); 3 = MFMAs only (no DMA, no reads); outputs are garbage for != 0.
+template <class T, bool B_KMAJOR, int ABL>
 __device__ __forceinline__ void run_shape(const MhGemmProblem* __restrict__ probs, const uint2* __restrict__ items, int n_items,
                                           int stride, int& i, uint2& item, int& slot, unsigned char* smem) {
     constexpr int MT = T::MT, PA = T::PA, PB = T::PB;
@@ -100,8 +102,10 @@ __device__ __forceinline__ void run_shape(const MhGemmProblem* __restrict__ prob
     // tile's LAST K step, i.e. every wave has finished reading the steps before that one: the two slots written here were
     // read three and two steps ago and are free, while the slot of the last step (possibly still being read by a slower
     // wave) is only refilled behind the barrier of this tile's first step.
-    issue_step(cur, 0, slot);
-    if (cur.nk > 1) issue_step(cur, 1, ring_next(slot));
+    if constexpr (ABL < 2) {
+        issue_step(cur, 0, slot);
+        if (cur.nk > 1) issue_step(cur, 1, ring_next(slot));
+    }
 
     while (true) {
         const int ni = i + stride;
@@ -135,22 +139,33 @@ __device__ __forceinline__ void run_shape(const MhGemmProblem* __restrict__ prob
             const unsigned char* ta = smem + slot * SLOT_BYTES;
             const unsigned char* tb = ta + T::A_BYTES;
             bf16x8 fa[MT], fb[4];
+            if constexpr (ABL == 0 || ABL == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR, T::BN>(tb, wn + 16 * j);
+                for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR, T::BN>(tb, wn + 16 * j);
 #pragma unroll
-            for (int ii = 0; ii < MT; ++ii) fa[ii] = read_frag<false, T::BM>(ta, wm + 16 * ii);
+                for (int ii = 0; ii < MT; ++ii) fa[ii] = read_frag<false, T::BM>(ta, wm + 16 * ii);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = __builtin_bit_cast(bf16x8, (u32x4){(uint32_t)t, (uint32_t)l, 0x3f803f80u, 0u});
+#pragma unroll
+                for (int ii = 0; ii < MT; ++ii) fa[ii] = __builtin_bit_cast(bf16x8, (u32x4){0x3f803f80u, (uint32_t)ii, (uint32_t)t, 0u});
+            }
             // (1) all fragment reads, (2) the DMA pieces that refill the slot vacated by the previous step -- with the step two
             // ahead of this one, which belongs to the NEXT tile of the run once this tile's K range is exhausted --, (3) MFMAs
             __builtin_amdgcn_sched_barrier(0);
             const int fill = slot == 0 ? PS - 1 : slot - 1;       // = (slot + PS - 1) % PS
-            if (t + PS - 1 < nk) issue_step(cur, t + PS - 1, fill);
-            else if (same && t + PS - 1 - nk < nxt.nk) issue_step(nxt, t + PS - 1 - nk, fill);
+            if constexpr (ABL < 2) {
+                if (t + PS - 1 < nk) issue_step(cur, t + PS - 1, fill);
+                else if (same && t + PS - 1 - nk < nxt.nk) issue_step(nxt, t + PS - 1 - nk, fill);
+            }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ABL != 1) {
 #pragma unroll
-            for (int ii = 0; ii < MT; ++ii)
+                for (int ii = 0; ii < MT; ++ii)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[j][ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[ii], acc[j][ii], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j)
+                        acc[j][ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[ii], acc[j][ii], 0, 0, 0);
+            }
             slot = ring_next(slot);
         }
         gemm_epilogue_store<MT, 16>(p, acc, st, m0 + wm, n0 + wn);
@@ -162,7 +177,7 @@ __device__ __forceinline__ void run_shape(const MhGemmProblem* __restrict__ prob
     }
 }
 
-template <bool B_KMAJOR>
+template <bool B_KMAJOR, int ABL>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_persist_kernel(const MhGemmProblem* __restrict__ probs,
                                                                    const uint2* __restrict__ items, int n_items) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];   // the ONLY LDS object: ring + epilogue staging
@@ -174,10 +189,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_persist_kernel(const MhGemmP
     uint2 item = items[i];
     while (i < n_items) {
         switch ((item.x >> 16) & 3) {
-            case MH_GTILE_256: run_shape<P256, B_KMAJOR>(probs, items, n_items, gridDim.x, i, item, slot, smem); break;
-            case MH_GTILE_128x256: run_shape<P128x256, B_KMAJOR>(probs, items, n_items, gridDim.x, i, item, slot, smem); break;
-            case MH_GTILE_256x128: run_shape<P256x128, B_KMAJOR>(probs, items, n_items, gridDim.x, i, item, slot, smem); break;
-            default: run_shape<P128, B_KMAJOR>(probs, items, n_items, gridDim.x, i, item, slot, smem); break;
+            case MH_GTILE_256: run_shape<P256, B_KMAJOR, ABL>(probs, items, n_items, gridDim.x, i, item, slot, smem); break;
+            case MH_GTILE_128x256: run_shape<P128x256, B_KMAJOR, ABL>(probs, items, n_items, gridDim.x, i, item, slot, smem); break;
+            case MH_GTILE_256x128: run_shape<P256x128, B_KMAJOR, ABL>(probs, items, n_items, gridDim.x, i, item, slot, smem); break;
+            default: run_shape<P128, B_KMAJOR, ABL>(probs, items, n_items, gridDim.x, i, item, slot, smem); break;
         }
     }
 }
@@ -225,8 +240,24 @@ extern "C" int mh_gemm_grouped(int layout, const MhGemmProblem* problems_device,
     MH_CHECK_ARG(n_workers >= 8 && n_workers % 8 == 0 && n_workers <= 4096, "mh_gemm_grouped: n_workers must be a multiple of 8 (%d)", n_workers);
     MH_CHECK_ARG((uintptr_t)items_device % 8 == 0, "mh_gemm_grouped: items must be 8-byte aligned");
     const uint2* items = reinterpret_cast<const uint2*>(items_device);
-    if (layout == 0) hipLaunchKernelGGL(gemm_persist_kernel<false>, dim3(n_workers), dim3(NTHREADS), 0, (hipStream_t)stream, problems_device, items, n_items);
-    else hipLaunchKernelGGL(gemm_persist_kernel<true>, dim3(n_workers), dim3(NTHREADS), 0, (hipStream_t)stream, problems_device, items, n_items);
+    if (layout == 0) hipLaunchKernelGGL((gemm_persist_kernel<false, 0>), dim3(n_workers), dim3(NTHREADS), 0, (hipStream_t)stream, problems_device, items, n_items);
+    else hipLaunchKernelGGL((gemm_persist_kernel<true, 0>), dim3(n_workers), dim3(NTHREADS), 0, (hipStream_t)stream, problems_device, items, n_items);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+// Diagnostic builds of the NT kernel (not part of the ABI in include/maestro_hip.h; outputs are garbage): see ABL above.
+extern "C" int mh_gemm_grouped_ablate(int ablate, const MhGemmProblem* problems_device, const uint32_t* items_device, int n_items,
+                                      int n_workers, void* stream) {
+    const uint2* items = reinterpret_cast<const uint2*>(items_device);
+    dim3 g(n_workers), b(NTHREADS);
+    hipStream_t s = (hipStream_t)stream;
+    switch (ablate) {
+        case 1: hipLaunchKernelGGL((gemm_persist_kernel<false, 1>), g, b, 0, s, problems_device, items, n_items); break;
+        case 2: hipLaunchKernelGGL((gemm_persist_kernel<false, 2>), g, b, 0, s, problems_device, items, n_items); break;
+        case 3: hipLaunchKernelGGL((gemm_persist_kernel<false, 3>), g, b, 0, s, problems_device, items, n_items); break;
+        default: hipLaunchKernelGGL((gemm_persist_kernel<false, 0>), g, b, 0, s, problems_device, items, n_items); break;
+    }
     MH_LAUNCH_CHECK();
     return 0;
 }

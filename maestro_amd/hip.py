@@ -730,3 +730,75 @@ class GroupedGemm:
         call("mh_gemm_grouped", _I(self.layout), self.table, _I(self.n), self.items, _I(self.n_items), _I(self.n_workers))
         if ev is not None:
             ev[1].record()
+
+
+# ------------------------------------------------------------------------------------------------ fp8 path (C5)
+FP8_E4M3, FP8_E5M2 = 0, 1
+FP8_MAX = {FP8_E4M3: 448.0, FP8_E5M2: 57344.0}
+QCHUNK = 4096   # elements per work item of mh_quant_batched (csrc/quant.hip)
+
+
+def gemm_fp8(M, N, K, A8, lda, B8, ldb, C, ldc, descale_a, descale_b, flags=0, a_format=FP8_E4M3, bias=None, res=None, ldr=0,  # noqa: N803
+             aux_in=None, aux_out=None, ldaux=0, colsum=None, c8=None, ldc8=0, c8_scale=None, c8_amax=None) -> None:
+    """``C = descale_a * descale_b * A8 @ B8^T`` (+ epilogue): A8 ``[M, K]`` / B8 ``[N, K]`` uint8 tensors holding OCP fp8."""
+    ev = None
+    if _timer is not None:
+        ev = _timer.record("gemm_fp8_kernel", 2.0 * M * N * K, (M, N, K))
+        ev[0].record()
+    _check(lib().mh_gemm_fp8(_I(M), _I(N), _I(K), ptr(A8), _I(lda), _I(a_format), ptr(B8), _I(ldb), ptr(C), _I(ldc), _I(flags),
+                             ptr(descale_a), ptr(descale_b), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux),
+                             ptr(colsum), ptr(c8), _I(ldc8), ptr(c8_scale), ptr(c8_amax), stream()), "mh_gemm_fp8")
+    if ev is not None:
+        ev[1].record()
+
+
+class _MhQuantJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dst_t", ctypes.c_void_p), ("n", ctypes.c_long),
+                ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("slot", ctypes.c_int), ("is_f32", ctypes.c_int),
+                ("format", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+class Fp8Scales:
+    """Scale / descale / amax tables (one slot per quantised tensor), all on the device."""
+
+    def __init__(self, n_slots: int, device) -> None:
+        self.n = n_slots
+        self.scale = torch.ones(n_slots, dtype=torch.float32, device=device)
+        self.descale = torch.ones(n_slots, dtype=torch.float32, device=device)
+        self.amax = torch.zeros(n_slots, dtype=torch.float32, device=device)
+
+    def update(self, lo: int = 0, hi: int | None = None, fmt: int = FP8_E4M3, margin: int = 1) -> None:
+        """``scale = 2^(floor(log2(max / amax)) - margin)`` for slots ``lo .. hi-1``; resets their amax."""
+        hi = self.n if hi is None else hi
+        call("mh_fp8_update_scales", self.amax[lo:hi], self.scale[lo:hi], self.descale[lo:hi], _I(hi - lo), _F(FP8_MAX[fmt]),
+             _I(margin))
+
+
+class QuantBatch:
+    """Job table for ``mh_quant_batched``: ``jobs`` = dicts(src, dst=None, dst_t=None, slot, format=FP8_E4M3); a transposed copy
+    needs a 2-D ``src``.  ``launch(mode)``: 0 absmax only, 1 cast, 2 cast + absmax (delayed scaling)."""
+
+    def __init__(self, jobs, scales: Fp8Scales, device) -> None:
+        arr = (_MhQuantJob * len(jobs))()
+        items, self.keep = [], []
+        for i, jb in enumerate(jobs):
+            src, dst, dst_t = jb["src"], jb.get("dst"), jb.get("dst_t")
+            n = src.numel()
+            if n % 4 or not src.is_contiguous() or src.dtype not in (torch.float32, torch.bfloat16):
+                raise HipExtensionError("QuantBatch: contiguous f32 / bf16 sources with numel % 4 == 0 expected")
+            rows, cols = (src.shape[0], n // src.shape[0]) if src.dim() >= 2 else (1, n)
+            if dst_t is not None and (cols % 4 or dst_t.numel() != n):
+                raise HipExtensionError("QuantBatch: the transposed copy needs cols % 4 == 0 and as many bytes as elements")
+            if dst is not None and dst.numel() != n:
+                raise HipExtensionError("QuantBatch: dst must hold one byte per source element")
+            arr[i] = _MhQuantJob(src.data_ptr(), dst.data_ptr() if dst is not None else None,
+                                 dst_t.data_ptr() if dst_t is not None else None, n, rows, cols, jb["slot"],
+                                 int(src.dtype == torch.float32), jb.get("format", FP8_E4M3), 0)
+            items += [(i << 32) | c for c in range(-(-n // QCHUNK))]
+            self.keep += [t for t in (src, dst, dst_t) if t is not None]
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        self.items = torch.tensor(items, dtype=torch.int64).to(device)
+        self.scales, self.n_items = scales, len(items)
+
+    def launch(self, mode: int) -> None:
+        call("mh_quant_batched", self.table, self.items, _I(self.n_items), self.scales.scale, self.scales.amax, _I(mode))
