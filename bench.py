@@ -46,6 +46,7 @@ SUP_WORKLOADS = {
                ds=lambda: conf.DatasetsConfig(name_dataset="treesatai_ts", treesatai_ts=conf.TreeSatAITSConfig())),
 }
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (block-scaled MFMA 16x16x128), same guide
 HBM_PEAK_TBS = 8.0          # HBM3E, same guide
 
 
@@ -229,6 +230,8 @@ def main() -> None:
     ap.add_argument("--config", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU (reference default, conf/opt.py:20)")
     ap.add_argument("--loss", default="l2_norm")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="GEMM operand type: bf16 (BASELINE metric), fp8 = e4m3 forward GEMMs (BASELINE configs[4]: --config c5)")
     ap.add_argument("--phase", default="pretrain", choices=["pretrain", "probe", "finetune"],
                     help="pretrain = the BASELINE metric; probe / finetune = the supervised branch (configs c3, c4)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline sample (0 = skip)")
@@ -281,7 +284,7 @@ def main() -> None:
     if args.phase == "pretrain":
         loop = PretrainLoop(model, args.batch, dev, loss=args.loss, total_steps=args.steps + args.warmup, world_size=world,
                             exchange=True if args.rehearse_exchange else None,
-                            overlap_optimizer=args.overlap_optimizer)
+                            overlap_optimizer=args.overlap_optimizer, dtype=args.dtype)
     else:
         loop = SupervisedLoop(model, args.batch, dev, phase=args.phase, total_steps=args.steps + args.warmup, world_size=world)
     batch = synthetic_batch(ds.dataset, args.batch, dev, seed=rank)
@@ -364,7 +367,7 @@ def main() -> None:
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "step_ms": {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3),
                         "max": round(step_ms[-1], 3), "how": "HIP events on the main stream at every step boundary (this rank)"},
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic" if not args.from_host else "synthetic, fed from pinned host memory every step (PCIe-inclusive)",
             "config": {"workload": f"{args.config}: {w['desc']}", "tiles_per_gpu": args.batch,
                        "global_batch": args.batch * world, "loss": args.loss if args.phase == "pretrain" else "loss_pred",
@@ -374,8 +377,19 @@ def main() -> None:
             "whole_step": {"train_gflop_per_tile": w["gflop_tile"],
                            "mfma_frac": round(value / world * w["gflop_tile"] / 1e3 / MFMA_PEAK_TFLOPS, 4)},
         }
+        if args.dtype == "fp8":
+            out["config"]["precision"] = ("forward GEMMs of the transformer layers: OCP e4m3 operands, scaled MFMA 16x16x128, fp32 "
+                                          "accumulate, per-tensor delayed scaling; backward GEMMs and attention bf16; fp32 masters")
         if timer is not None:
             out["roofline"] = timer.roofline(MFMA_PEAK_TFLOPS)
+            if out["roofline"]["kernel"] == "gemm_fp8_kernel":     # price an fp8 kernel against the fp8 MFMA peak
+                out["roofline"].update(peak=FP8_PEAK_TFLOPS, frac=round(out["roofline"]["achieved"] / FP8_PEAK_TFLOPS, 4))
+            elif args.dtype == "fp8":
+                tot = timer.totals()
+                ach = timer.flops["gemm_fp8_kernel"] / (tot["gemm_fp8_kernel"] * 1e-3) / 1e12
+                out["roofline_fp8_kernel"] = {"bound": "mfma", "kernel": "gemm_fp8_kernel", "achieved": round(ach, 1),
+                                              "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP8_PEAK_TFLOPS, 4),
+                                              "launches": timer.count["gemm_fp8_kernel"]}
             traffic_file = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
             # PMC passes are separate runs (rocprofv3 --pmc) of the DEFAULT workload: the committed summary applies to it only
             if os.path.exists(traffic_file) and args.phase == "pretrain" and args.config == "c3" and args.batch == 32:

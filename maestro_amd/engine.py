@@ -163,6 +163,21 @@ class Stack:
         self.ln_rows = hip.layernorm_bwd_workspace(M, dim) // (3 * dim)
         for s in self.saved:
             s.update(ws1=e(self.ln_rows, 3 * dim), ws2=e(self.ln_rows, 3 * dim), cs=e(self.cs_rows, mlp))
+        # fp8 forward (maestro_amd/fp8.py): e4m3 copies of the four GEMM A operands of every layer + weight shadows
+        plan = getattr(eng, "fp8", None)
+        self.f8 = None
+        if plan is not None and all(plan.eligible(k) for k in (dim, self.inner, mlp)):
+            self.f8 = []
+            for (attn, ff) in holder.layers:
+                d = dict(h1=e(M, dim, dt=U8), o=e(M, self.inner, dt=U8), h2=e(M, dim, dt=U8), act=e(M, mlp, dt=U8),
+                         s_h1=plan.add_activation(), s_o=plan.add_activation(), s_h2=plan.add_activation(),
+                         s_act=plan.add_activation())
+                for key, lin in (("qkv", attn.to_qkv), ("proj", attn.to_out[0]), ("fc1", ff.net[1]), ("fc2", ff.net[4])):
+                    cache = eng._fp8_weights.get(id(lin.weight))
+                    if cache is None:        # a holder shared by several groups registers its weights once
+                        cache = eng._fp8_weights[id(lin.weight)] = plan.add_weight(lin.weight.data)
+                    d["w_" + key], d["sw_" + key] = cache
+                self.f8.append(d)
 
     @property
     def x0(self):
@@ -189,6 +204,9 @@ class Stack:
             if before_layer is not None:
                 before_layer(l)
             s, x_in, x_mid, x_out = self.saved[l], self.xs[2 * l], self.xs[2 * l + 1], self.xs[2 * l + 2]
+            if self.f8 is not None:
+                self._forward_layer_fp8(l, attn, ff, s, x_in, x_mid, x_out)
+                continue
             hip.layernorm_fwd(x_in, M, 0, attn.norm.weight, attn.norm.bias, s["h1"], M, 0, s["mean1"], s["rstd1"], 1, M, dim)
             hip.gemm(hip.GEMM_NT, M, 3 * inner, dim, s["h1"], dim, ps.h(attn.to_qkv.weight), dim, s["qkv"], 3 * inner)
             hip.attn_fwd(s["qkv"], s["o"], s["lse"], self.Bn, self.N, self.H, self.Dh, attn.scale)
@@ -202,6 +220,28 @@ class Stack:
                      hip.BIAS | hip.GELU | hip.AUX_DGELU, bias=fc1.bias, aux_out=s["hpre"], ldaux=mlp)
             hip.gemm(hip.GEMM_NT, M, dim, mlp, s["act"], mlp, ps.h(fc2.weight), mlp, x_out, dim,
                      hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=fc2.bias, res=x_mid, ldr=dim)
+
+    def _forward_layer_fp8(self, l, attn, ff, s, x_in, x_mid, x_out) -> None:
+        """The layer's forward with e4m3 GEMM operands (bf16 copies of the activations are still written: the backward reads
+        them).  Same kernels otherwise; the GELU output's e4m3 copy comes straight out of the fc1 epilogue."""
+        eng, M, dim, mlp, inner = self.eng, self.M, self.dim, self.mlp, self.inner  # noqa: N806
+        plan, f = eng.fp8, self.f8[l]
+        proj, ln2, fc1, fc2 = attn.to_out[0], ff.net[0], ff.net[1], ff.net[4]
+        hip.layernorm_fwd(x_in, M, 0, attn.norm.weight, attn.norm.bias, s["h1"], M, 0, s["mean1"], s["rstd1"], 1, M, dim)
+        plan.quantize(s["h1"], f["h1"], f["s_h1"])
+        hip.gemm_fp8(M, 3 * inner, dim, f["h1"], dim, f["w_qkv"], dim, s["qkv"], 3 * inner, plan.a_descale(f["s_h1"]),
+                     plan.w_descale(f["sw_qkv"]))
+        hip.attn_fwd(s["qkv"], s["o"], s["lse"], self.Bn, self.N, self.H, self.Dh, attn.scale)
+        plan.quantize(s["o"], f["o"], f["s_o"])
+        hip.gemm_fp8(M, dim, inner, f["o"], inner, f["w_proj"], inner, x_mid, dim, plan.a_descale(f["s_o"]),
+                     plan.w_descale(f["sw_proj"]), flags=hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=proj.bias, res=x_in, ldr=dim)
+        hip.layernorm_fwd(x_mid, M, 0, ln2.weight, ln2.bias, s["h2"], M, 0, s["mean2"], s["rstd2"], 1, M, dim)
+        plan.quantize(s["h2"], f["h2"], f["s_h2"])
+        hip.gemm_fp8(M, mlp, dim, f["h2"], dim, f["w_fc1"], dim, s["act"], mlp, plan.a_descale(f["s_h2"]),
+                     plan.w_descale(f["sw_fc1"]), flags=hip.BIAS | hip.GELU | hip.AUX_DGELU, bias=fc1.bias, aux_out=s["hpre"],
+                     ldaux=mlp, c8=f["act"], ldc8=mlp, c8_scale=plan.a_scale(f["s_act"]), c8_amax=plan.a_amax(f["s_act"]))
+        hip.gemm_fp8(M, dim, mlp, f["act"], mlp, f["w_fc2"], mlp, x_out, dim, plan.a_descale(f["s_act"]),
+                     plan.w_descale(f["sw_fc2"]), flags=hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=fc2.bias, res=x_mid, ldr=dim)
 
     def reduce_jobs(self, lo: int = 0, hi: int | None = None) -> list:
         """``hip.ColsumBatch`` jobs of layers ``lo .. hi-1`` after a ``backward(defer=True)``: the LayerNorm partial rows
@@ -552,14 +592,17 @@ class EngineBase:
 
 # ======================================================================================= the engine
 class MAEEngine(EngineBase):
-    def __init__(self, model, batch_size: int, device, loss: str = "l2_norm") -> None:
+    def __init__(self, model, batch_size: int, device, loss: str = "l2_norm", dtype: str = "bf16") -> None:
         if loss not in ("l1", "l2", "l1_norm", "l2_norm"):
             raise ValueError(f"Invalid loss {loss}.")
+        if dtype not in ("bf16", "fp8"):
+            raise ValueError(f"Invalid compute dtype {dtype!r} (bf16, fp8)")
         device = torch.device(device)
         if device.type != "cuda":
             raise hip.HipExtensionError("MAEEngine needs a GPU device; the MAE hot path has no CPU fallback")
         hip.lib()  # fail loudly now if the extension is missing
-        self.model, self.B, self.device, self.loss = model, batch_size, device, loss
+        self.model, self.B, self.device, self.loss, self.dtype = model, batch_size, device, loss, dtype
+        self.fp8, self._fp8_weights = None, {}
         self.p_loss = 1 if loss.startswith("l1") else 2
         self.normalise = loss.endswith("_norm")
         m = model
@@ -604,7 +647,12 @@ class MAEEngine(EngineBase):
         self.store = ParamStore(ordered, device)
         for bname in ("enc_pos_encoding", "dec_pos_encoding"):
             setattr(m, bname, getattr(m, bname).to(device))
+        if dtype == "fp8":
+            from maestro_amd.fp8 import Fp8Plan
+            self.fp8 = Fp8Plan(device)
         self._alloc()
+        if self.fp8 is not None:
+            self.fp8.finalize()
         self.store.refresh_half(force=True)
         self._pack_conv_weights()
 
@@ -672,9 +720,14 @@ class MAEEngine(EngineBase):
         self.loss_w = {n: (s.Dates * s.L) / tot_w for n, s in self.mods.items()}  # weight = D*H*W (model.py:239)
 
     def _pack_conv_weights(self) -> None:
+        """Derived weight copies beyond the flat bf16 shadow (called wherever the shadows are refreshed: engine start,
+        parameters changed behind the engine's back, after every fused AdamW step): the K-padded patch-embed weights and,
+        in fp8 mode, the e4m3 weight shadows with their scales."""
         for name, s in self.mods.items():
             b = self.mb[name]
             hip.pack_rows_bf16(b["pe"].conv.weight, b["w_conv16"], self.E, s.K, s.Kpad)
+        if self.fp8 is not None:
+            self.fp8.refresh_weights()
 
     # ------------------------------------------------------------------------------------------ RNG (host)
     def draw_masks(self, generator=None):
@@ -948,6 +1001,8 @@ class MAEEngine(EngineBase):
             self._run_parallel([tail(g) for g in self.groups])
         if self._opt is not None and self._opt_events:
             torch.cuda.current_stream().wait_stream(self._opt_stream)   # join (a capture must end with every fork joined)
+        if self.fp8 is not None:
+            self.fp8.end_of_forward()
 
     # ------------------------------------------------------------------------------------------ backward
     def zero_grad(self) -> None:

@@ -1,0 +1,88 @@
+"""fp8 operand plan of the step engine (BASELINE configs[4]: "ViT-Base MAE fp8 MFMA path", S2-NAIP-urban shapes).
+
+What runs in fp8: the four forward GEMMs of every transformer layer (qkv, out-proj, fc1, fc2 of ``vit_pytorch``'s Attention /
+FeedForward, call sites ``maestro/ssl/mae.py:135-174``) -- OCP e4m3 operands, ``v_mfma_scale_f32_16x16x128_f8f6f4`` with unit
+block scales, fp32 accumulation, per-TENSOR power-of-two scales (``csrc/gemm_fp8.hip``, ``csrc/quant.hip``).  What stays bf16:
+the backward (dgrad and the grouped weight gradients read the bf16 copies of the activations that the forward keeps writing),
+attention, the patch-embed / enc_to_dec / pixelify GEMMs.  Master weights, residual stream, LayerNorm, softmax, loss: fp32.
+
+Scaling (all state on the device, nothing is read by the host, capturable in the step's hipGraphs):
+  * weights:     after every optimizer step ``absmax -> scale = 2^(floor(log2(448 / amax)) - 1) -> cast`` (three launches
+                 over all weight tensors);
+  * activations: delayed scaling -- step t casts with the scale derived from step t-1's absmax and records its own absmax
+                 (LayerNorm outputs, attention outputs: ``mh_quant_batched`` mode 2; GELU outputs: the fc1 epilogue writes the
+                 e4m3 copy itself); the first step runs with scale 1.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from maestro_amd import hip
+
+U8 = torch.uint8
+
+
+class Fp8Plan:
+    def __init__(self, device) -> None:
+        self.device = device
+        self._w_jobs, self._n_act = [], 0
+        self.wsc = self.asc = None
+        self._wbatch = None
+        self._abatch: dict = {}
+
+    # ---- registration (while the engine allocates its buffers)
+    @staticmethod
+    def eligible(K: int) -> bool:  # noqa: N803
+        return K % 128 == 0 and K >= 128
+
+    def add_weight(self, master: torch.Tensor):
+        """``master``: the fp32 parameter view [N, K] inside the flat buffer -> (e4m3 shadow uint8 [N, K], scale slot)."""
+        w8 = torch.zeros(master.shape, dtype=U8, device=self.device)
+        slot = len(self._w_jobs)
+        self._w_jobs.append(dict(src=master, dst=w8, slot=slot, format=hip.FP8_E4M3))
+        return w8, slot
+
+    def add_activation(self) -> int:
+        self._n_act += 1
+        return self._n_act - 1
+
+    def finalize(self) -> None:
+        self.wsc = hip.Fp8Scales(max(1, len(self._w_jobs)), self.device)
+        self.asc = hip.Fp8Scales(max(1, self._n_act), self.device)
+        if self._w_jobs:
+            self._wbatch = hip.QuantBatch(self._w_jobs, self.wsc, self.device)
+
+    # ---- per step
+    def refresh_weights(self) -> None:
+        """absmax -> scales -> e4m3 shadows of every registered weight (call after the fp32 masters changed)."""
+        if self._wbatch is None:
+            return
+        self._wbatch.launch(0)
+        self.wsc.update(fmt=hip.FP8_E4M3, margin=1)
+        self._wbatch.launch(1)
+
+    def quantize(self, src: torch.Tensor, dst: torch.Tensor, slot: int) -> None:
+        """Activation cast with the current scale of ``slot`` + absmax for the next step (delayed scaling)."""
+        key = (src.data_ptr(), dst.data_ptr(), slot)
+        qb = self._abatch.get(key)
+        if qb is None:
+            qb = self._abatch[key] = hip.QuantBatch([dict(src=src, dst=dst, slot=slot, format=hip.FP8_E4M3)], self.asc, self.device)
+        qb.launch(2)
+
+    def end_of_forward(self) -> None:
+        """Derive the next step's activation scales from this step's absmax values."""
+        if self._n_act:
+            self.asc.update(fmt=hip.FP8_E4M3, margin=1)
+
+    def a_scale(self, slot):
+        return self.asc.scale[slot: slot + 1]
+
+    def a_descale(self, slot):
+        return self.asc.descale[slot: slot + 1]
+
+    def a_amax(self, slot):
+        return self.asc.amax[slot: slot + 1]
+
+    def w_descale(self, slot):
+        return self.wsc.descale[slot: slot + 1]

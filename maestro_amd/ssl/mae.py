@@ -211,15 +211,20 @@ class MAE(nn.Module):
         self.pos_dec_rows = {m: pool_pos_table(self.dec_pos_encoding.cpu(), s.g) for m, s in self.mod_specs.items()}
 
     # ------------------------------------------------------------------------------------------ engine plumbing
-    def engine(self, batch_size: int, device=None, loss: str = "l2_norm"):
-        """Return (building on first use / batch-size change) the HIP step engine bound to these parameters."""
+    def engine(self, batch_size: int, device=None, loss: str = "l2_norm", dtype: str | None = None):
+        """Return (building on first use / batch-size change) the HIP step engine bound to these parameters.  ``dtype``:
+        "bf16" (default) or "fp8" (e4m3 forward GEMMs, maestro_amd/fp8.py); None keeps the current engine's / MAESTRO_DTYPE."""
+        import os
+
         from maestro_amd.engine import MAEEngine
 
         device = torch.device(device) if device is not None else next(self.parameters()).device
+        if dtype is None:
+            dtype = self._engine.dtype if self._engine is not None else os.environ.get("MAESTRO_DTYPE", "bf16")
         if self._engine is None or self._engine.B != batch_size or self._engine.loss != loss \
-                or self._engine.device != device:
+                or self._engine.device != device or self._engine.dtype != dtype:
             self._sup_engine = None
-            self._engine = MAEEngine(self, batch_size, device, loss=loss)
+            self._engine = MAEEngine(self, batch_size, device, loss=loss, dtype=dtype)
         return self._engine
 
     def sup_engine(self, batch_size: int, device=None, phase: str = "finetune"):

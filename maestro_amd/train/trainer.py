@@ -32,8 +32,10 @@ class PretrainLoop:
     def __init__(self, model, batch_size: int, device, loss: str = "l2_norm", base_lr: float = 3e-5,
                  betas=(0.9, 0.99), weight_decay: float = 0.01, total_steps: int = 1000, world_size: int = 1,
                  final_factor: float = 1e7, bucket_mb: int = 64, exchange: bool | None = None,
-                 accumulate: int = 1, overlap_optimizer: bool = False, bucket_dtype=None) -> None:
-        self.engine = model.engine(batch_size, device, loss=loss)
+                 accumulate: int = 1, overlap_optimizer: bool = False, bucket_dtype=None, dtype: str | None = None) -> None:
+        self.engine = model.engine(batch_size, device, loss=loss, dtype=dtype)
+        if overlap_optimizer and self.engine.fp8 is not None:
+            raise ValueError("overlap_optimizer is not available with dtype='fp8' (the e4m3 weight shadows are rebuilt after the update)")
         broadcast_parameters(self.engine)   # every rank starts from rank 0's weights (what Lightning's DDP wrap does)
         lr = scaled_lr(base_lr, batch_size, accumulate, 1, world_size)   # model.py:120-128: micro-batches count towards the batch
         self.sched = OneCycle(lr, max(total_steps, 2), pct_start=0.2, div_factor=1000.0,

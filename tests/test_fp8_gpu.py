@@ -87,8 +87,12 @@ def test_gemm_fp8_epilogues_match_bf16_kernel(dev):
     torch.cuda.synchronize()
     assert (C8.float() - C16.float()).abs().max() <= 2e-2 * C16.float().abs().max() and (X8.float() - X16.float()).abs().max() < 2e-2
     assert (C8.float() - C16.float()).abs().mean() < 1e-4          # identical but for a few bf16 rounding flips
-    want8 = _q((C8.float() * 8.0).clamp(-448, 448), 0).view(torch.uint8)
-    assert torch.equal(c8.cpu(), want8.cpu()) and abs(float(amax) - float(C8.float().abs().max())) < 1e-6
+    # the e4m3 copy is cast from the fp32 epilogue value, C8 from the same value rounded to bf16 first: re-quantising C8 lands
+    # on the same code except where the bf16 rounding crossed an e4m3 boundary (neighbouring code, a few per cent at most)
+    want8 = _q((C8.float() * 8.0).clamp(-448, 448), 0).view(torch.uint8).cpu().int()
+    diff = (c8.cpu().int() - want8).abs()
+    assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 0.05, (int(diff.max()), float((diff != 0).float().mean()))
+    assert abs(float(amax) - float(C8.float().abs().max())) <= 2 ** -7 * float(amax)
     # proj / fc2-style: fp32 out + bias + residual
     D8, D16 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)  # noqa: N806
     fl = hip.OUT_F32 | hip.BIAS | hip.RESIDUAL
@@ -96,3 +100,79 @@ def test_gemm_fp8_epilogues_match_bf16_kernel(dev):
     hip.gemm(hip.GEMM_NT, M, N, K, A16, K, B16, K, D16, N, fl, bias=bias, res=res, ldr=N)
     torch.cuda.synchronize()
     assert (D8 - D16).abs().max() < 1e-4
+
+
+COMMON = dict(interpolate="nearest", model="mae", num_levels=1, type_head="attentive", fac_abs_enc=1.0, fac_date_enc=1.0)
+# fp8 forward (e4m3, 3 mantissa bits) against the fp32 oracle: observed on MI355X (round 2) loss 2.1e-3, pixels_rec 3.6e-2,
+# worst gradient 0.11 -- tolerances <= 3x; the bf16 engine on the same case: 6e-4 / 5e-3 / 1.5e-2
+FP8_LOSS_TOL, FP8_PIX_TOL, FP8_GRAD_TOL = 1.5e-2, 1.0e-1, 3.0e-1
+
+
+def test_engine_fp8_forward_matches_oracle(dev, observed):
+    """The whole step with e4m3 forward GEMMs (maestro_amd/fp8.py) against the fp32 oracle, same weights / inputs / draws:
+    masks bit-exact, loss, reconstructions and every parameter gradient within the stated fp8 tolerances; a second forward
+    (scales now derived from the first step's absmax) stays as close; one AdamW step refreshes the e4m3 weight shadows."""
+    import maestro_amd.conf as conf
+    from maestro_amd.ssl import mae as pmae
+    from maestro_amd.train.optim import FusedAdamW
+    from oracle import mae as om
+    from oracle.gen_golden import build_datasets, case_table, init_weights, make_batch
+    case = dict(case_table()["c3_aerial_s2"])
+    ds = build_datasets(case, conf)
+    kw = dict(fusion_mode="group", inter_depth=1, depth=3, **COMMON)
+    oracle = om.build_oracle(ds, conf.MaskConfig(), model_size="small", **kw)       # E = 384 = 3 x 128: fp8-eligible widths
+    init_weights(oracle, 77)
+    model = pmae.mae_small(datasets=ds, mask=conf.MaskConfig(), **kw)
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    B = 4  # noqa: N806
+    batch = make_batch(ds.dataset, B, 5)
+    eng = model.engine(B, dev, loss="l2_norm", dtype="fp8")
+    assert eng.fp8 is not None and all(st.f8 is not None for st in eng._all_stacks())
+    torch.manual_seed(3)
+    noise, struct = eng.draw_masks()
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    loss = eng.forward(dbatch, noise=noise, struct=struct)
+    eng.zero_grad()
+    eng.backward()
+    torch.cuda.synchronize()
+    pixels, masks = eng.reconstructions()
+    ob, orec, omsk, _ = oracle({k: v.clone() for k, v in batch.items()}, "pretrain", noise=noise,
+                               struct_masks={g: s[:, :, None] for g, s in struct.items()})
+    oloss = om.compute_loss_rec(ob, orec, omsk, oracle.out_grid_size, om.norm_bands_of(ds.dataset), "l2_norm")
+    oracle.zero_grad()
+    oloss.backward()
+    rel = lambda a, b: ((a - b).double().norm() / b.double().norm().clamp(min=1e-12)).item()  # noqa: E731
+    for m in orec:
+        assert torch.equal(masks[m].cpu(), omsk[m])
+        e = rel(pixels[m].cpu(), orec[m].detach())
+        observed("fp8/small", f"pixels/{m}", e)
+        assert e < FP8_PIX_TOL, (m, e)
+    e = abs(loss.item() - oloss.item()) / abs(oloss.item())
+    observed("fp8/small", "loss", e)
+    assert e < FP8_LOSS_TOL, (loss.item(), oloss.item())
+    ograds = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
+    gmax = max(g.abs().max().item() for g in ograds.values())
+    worst = (0.0, None)
+    for k, p in model.named_parameters():
+        if k in ograds:
+            got, want = eng.store.g(p).cpu(), ograds[k]
+            err, ref = (got - want).double().norm().item(), want.double().norm().item()
+            floor = 1e-4 * gmax * want.numel() ** 0.5
+            if ref > 10 * floor and err / ref > worst[0]:
+                worst = (err / ref, k)
+            assert err <= FP8_GRAD_TOL * ref + floor, (k, err / max(ref, 1e-12))
+    observed("fp8/small", f"grad_worst/{worst[1]}", worst[0])
+    # second forward: activation scales are now derived from the first step's absmax (delayed scaling)
+    assert float(eng.fp8.asc.scale.max()) > 1.0 or float(eng.fp8.asc.scale.min()) < 1.0
+    loss2 = eng.forward(dbatch, noise=noise, struct=struct)
+    e2 = abs(loss2.item() - oloss.item()) / abs(oloss.item())
+    observed("fp8/small", "loss_step2", e2)
+    assert e2 < FP8_LOSS_TOL
+    # an optimizer step rebuilds the e4m3 weight shadows from the updated masters
+    w8_before = eng.enc["aerial"].f8[0]["w_qkv"].clone()
+    eng.zero_grad()
+    eng.backward()
+    FusedAdamW(eng, 1e-2).step()
+    loss3 = eng.forward(dbatch, noise=noise, struct=struct)
+    torch.cuda.synchronize()
+    assert not torch.equal(w8_before, eng.enc["aerial"].f8[0]["w_qkv"]) and loss3.item() < loss.item()
