@@ -233,35 +233,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     }
 }
 
-// =============================================================================================== delta = rowsum(dO * O)
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                         float* __restrict__ delta, int N, int H, int D, long total) {
-    // one thread group of D/8 lanes per (b, n, h) row
-    const int lanes = D / 8;
-    const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / lanes;
-    const int sub = threadIdx.x % lanes;
-    float s = 0.f;
-    if (gid < total) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(o + gid * D + sub * 8);
-        const u32x4 d = *reinterpret_cast<const u32x4*>(dout + gid * D + sub * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            s += __uint_as_float(a[e] << 16) * __uint_as_float(d[e] << 16);
-            s += __uint_as_float(a[e] & 0xffff0000u) * __uint_as_float(d[e] & 0xffff0000u);
-        }
-    }
-    for (int off = lanes >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (gid < total && sub == 0) {
-        const long bn = gid / H; const int h = gid - bn * H; const long b = bn / N; const int n = bn - b * N;
-        delta[((size_t)b * H + h) * N + n] = s;
-    }
-}
-
 // =============================================================================================== dQ
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                          float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H,
+                                                          float scale) {
     constexpr int KS = D / 32, DT = D / 16, TB = 64 * D * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * TB];  // K row | K transpose | V row
     unsigned char* k_row = smem;
@@ -281,6 +258,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     const bf16_t* kb = qb + (size_t)H * D;
     const bf16_t* vb = qb + (size_t)2 * H * D;
     const bf16_t* dob = dout + (size_t)b * N * os + (size_t)h * D;
+    const bf16_t* ob = out + (size_t)b * N * os + (size_t)h * D;
     const int q0 = q_blk + 32 * w;
 
     bf16x8 qf[2][KS], dof[2][KS];
@@ -288,13 +266,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + 16 * qt + lq;
+        // delta[q] = sum_d O[q, d] dO[q, d] is computed HERE (it used to be a launch of its own in front of the two backward
+        // kernels: 27 launches per step): the lane already holds its 8-element slices of dO, loads the matching slices of O,
+        // and the four lane groups that share a query fold their partial sums; lane group 0 also stores it for the dK / dV
+        // kernel, which runs behind this one on the stream.
+        float part = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qf[qt][ks] = frag_global(qb, rs, q, N, ks);
             dof[qt][ks] = frag_global(dob, os, q, N, ks);
+            const bf16x8 of = frag_global(ob, os, q, N, ks);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += (float)of[e] * (float)dof[qt][ks][e];
         }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
         lse2[qt] = q < N ? lse[((size_t)b * H + h) * N + q] * LOG2E : INFINITY;
-        dlt[qt] = q < N ? delta[((size_t)b * H + h) * N + q] : 0.f;
+        dlt[qt] = q < N ? part : 0.f;
+        if (q < N && g == 0) delta[((size_t)b * H + h) * N + q] = part;
     }
     f32x4 dq[2][DT];
 #pragma unroll
@@ -537,15 +526,12 @@ extern "C" int mh_attn_bwd(const void* qkv, const void* out, const void* dout, c
     MH_CHECK_ARG(qkv && out && dout && lse && delta && dqkv, "mh_attn_bwd: null pointer");
     MH_CHECK_ARG(B > 0 && N > 0 && H > 0 && (D == 32 || D == 64), "mh_attn_bwd: unsupported shape B=%d N=%d H=%d D=%d", B, N, H, D);
     hipStream_t s = (hipStream_t)stream;
-    const long rows = (long)B * N * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div(rows * (D / 8), 256)), dim3(256), 0, s, (const bf16_t*)out,
-                       (const bf16_t*)dout, delta, N, H, D, rows);
     dim3 grid(ceil_div(N, 128) * H * B), block(256);
     if (D == 64) {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
     } else {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
     }
     MH_LAUNCH_CHECK();

@@ -99,13 +99,13 @@ def test_gemm_fp8_epilogues_match_bf16_kernel(dev):
     hip.gemm_fp8(M, N, K, A8, K, B8, K, D8, N, one, one, flags=fl, bias=bias, res=res, ldr=N)
     hip.gemm(hip.GEMM_NT, M, N, K, A16, K, B16, K, D16, N, fl, bias=bias, res=res, ldr=N)
     torch.cuda.synchronize()
-    assert (D8 - D16).abs().max() < 1e-4
+    assert (D8 - D16).abs().max() < 1e-3      # fp32 sums of exact products, grouped by 128 instead of 32 along K
 
 
 COMMON = dict(interpolate="nearest", model="mae", num_levels=1, type_head="attentive", fac_abs_enc=1.0, fac_date_enc=1.0)
-# fp8 forward (e4m3, 3 mantissa bits) against the fp32 oracle: observed on MI355X (round 2) loss 2.1e-3, pixels_rec 3.6e-2,
-# worst gradient 0.11 -- tolerances <= 3x; the bf16 engine on the same case: 6e-4 / 5e-3 / 1.5e-2
-FP8_LOSS_TOL, FP8_PIX_TOL, FP8_GRAD_TOL = 1.5e-2, 1.0e-1, 3.0e-1
+# fp8 forward (e4m3, 3 mantissa bits) against the fp32 oracle: observed on MI355X (round 2) loss 4.2e-4, pixels_rec 5.6e-2,
+# worst parameter gradient 8.6e-2 (relative L2) -- tolerances <= 3x; the bf16 engine sits at 3.5e-4 / 7e-3 / 1.5e-2
+FP8_LOSS_TOL, FP8_PIX_TOL, FP8_GRAD_TOL = 1.2e-3, 1.5e-1, 2.5e-1
 
 
 def test_engine_fp8_forward_matches_oracle(dev, observed):
@@ -131,7 +131,7 @@ def test_engine_fp8_forward_matches_oracle(dev, observed):
     torch.manual_seed(3)
     noise, struct = eng.draw_masks()
     dbatch = {k: v.to(dev) for k, v in batch.items()}
-    loss = eng.forward(dbatch, noise=noise, struct=struct)
+    loss = eng.forward(dbatch, noise=noise, struct=struct).clone()     # (the engine's loss buffer is static: keep the value)
     eng.zero_grad()
     eng.backward()
     torch.cuda.synchronize()
@@ -164,7 +164,7 @@ def test_engine_fp8_forward_matches_oracle(dev, observed):
     observed("fp8/small", f"grad_worst/{worst[1]}", worst[0])
     # second forward: activation scales are now derived from the first step's absmax (delayed scaling)
     assert float(eng.fp8.asc.scale.max()) > 1.0 or float(eng.fp8.asc.scale.min()) < 1.0
-    loss2 = eng.forward(dbatch, noise=noise, struct=struct)
+    loss2 = eng.forward(dbatch, noise=noise, struct=struct).clone()
     e2 = abs(loss2.item() - oloss.item()) / abs(oloss.item())
     observed("fp8/small", "loss_step2", e2)
     assert e2 < FP8_LOSS_TOL
