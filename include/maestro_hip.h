@@ -142,6 +142,11 @@ int mh_fp8_update_scales(float* amax, float* scale, float* descale, int n, float
  * dim % 4 == 0, dim <= 2048. */
 int mh_layernorm_fwd(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y, int y_L,
                      int y_off, int y_is_f32, float* mean, float* rstd, int B, int n, int dim, float eps, void* stream);
+/* The same with a second output for the fp8 path: y8 = OCP e4m3 of (y * *y8_scale) in y's row map (the A operand of the next
+ * mh_gemm_fp8), max |y| folded into *y8_amax (optional; delayed scaling).  y is bf16 (the backward's wgrad reads it). */
+int mh_layernorm_fwd_fp8(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y, int y_L,
+                         int y_off, float* mean, float* rstd, int B, int n, int dim, float eps, void* y8,
+                         const float* y8_scale, float* y8_amax, void* stream);
 /* dx (f32, x's row map) = (dres ? dres : 0) + LN-backward(dy); optional bf16 copy dx_bf16 (operand of the next
  * dgrad/wgrad GEMM).  dgamma/dbeta f32 [dim] are accumulated (+=) through `workspace` (f32,
  * mh_layernorm_bwd_workspace(B*n, dim) floats; per-block partial rows, then a short atomic reduce); dcol f32 [dim]

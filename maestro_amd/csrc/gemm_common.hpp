@@ -33,7 +33,9 @@ __device__ __forceinline__ u32x2 pack_fp8x8(f32x4 lo, f32x4 hi, float s) {
     return (u32x2){(uint32_t)a, (uint32_t)b};
 }
 __device__ __forceinline__ void atomic_max_pos(float* dst, float v) {   // v >= 0: the int order of the bits is the float order
-    atomicMax(reinterpret_cast<int*>(dst), __float_as_int(v));
+    // thousands of workgroups fold into ONE word per tensor: look first (a possibly stale value only costs a redundant
+    // atomic, never a lost maximum) so that after the first few arrivals almost nobody issues the same-address atomic
+    if (v > __builtin_nontemporal_load(dst)) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(v));
 }
 
 // gemm_dma.hip: the LDS-DMA tile family (tile = MH_TILE_DMA_*); -2 = not eligible, nothing launched

@@ -3,8 +3,7 @@
 // shuffles for the reductions.  Rows are addressed through (sample, j) maps so that "split / concat of group
 // sequences" (reference mim.py:408-423) is done by addressing instead of copies:
 //     row(b, j) = b * L + off + j,  j < n.
-#include "common.hpp"
-#include "../../include/maestro_hip.h"
+#include "gemm_common.hpp"
 
 namespace {
 
@@ -16,7 +15,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, RowMap xm, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, void* __restrict__ y, RowMap ym,
                                                      int y_is_f32, float* __restrict__ mean, float* __restrict__ rstd,
-                                                     int B, int n, int dim, float eps) {
+                                                     int B, int n, int dim, float eps, uint8_t* __restrict__ y8,
+                                                     const float* __restrict__ y8_scale, float* __restrict__ y8_amax) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= B * n) return;
@@ -44,6 +44,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float rs = rsqrtf(wave_sum(q) / dim + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     const size_t yrow = map_row(ym, b, j) * dim;
+    const float s8 = y8 ? *y8_scale : 0.f;     // fp8 path: an e4m3 copy of the output (the next GEMM's A operand) + its absmax
+    float amax8 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
@@ -59,7 +61,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
                 *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(y) + yrow + 4 * c) = pk;
             }
+            if (y8) {
+                f32x4 q8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    amax8 = fmaxf(amax8, fabsf(o[e]));
+                    q8[e] = fminf(fmaxf(o[e] * s8, -448.f), 448.f);
+                }
+                int a = __builtin_amdgcn_cvt_pk_fp8_f32(q8[0], q8[1], 0, false);
+                a = __builtin_amdgcn_cvt_pk_fp8_f32(q8[2], q8[3], a, true);
+                *reinterpret_cast<uint32_t*>(y8 + yrow + 4 * c) = (uint32_t)a;
+            }
         }
+    }
+    if (y8 && y8_amax) {
+        amax8 = wave_max(amax8);
+        if (lane == 0 && amax8 > 0.f) atomic_max_pos(y8_amax, amax8);
     }
 }
 
@@ -219,9 +236,27 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(const MhColsumJob* 
 
 static int ln_nv(int dim) { const int v = (dim / 4 + 63) / 64; return v <= 4 ? v : 8; }
 
+static int layernorm_fwd_impl(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y, int y_L,
+                              int y_off, int y_is_f32, float* mean, float* rstd, int B, int n, int dim, float eps, void* y8,
+                              const float* y8_scale, float* y8_amax, void* stream);
+
 extern "C" int mh_layernorm_fwd(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y,
                                 int y_L, int y_off, int y_is_f32, float* mean, float* rstd, int B, int n, int dim,
                                 float eps, void* stream) {
+    return layernorm_fwd_impl(x, x_L, x_off, gamma, beta, y, y_L, y_off, y_is_f32, mean, rstd, B, n, dim, eps, nullptr, nullptr,
+                              nullptr, stream);
+}
+
+extern "C" int mh_layernorm_fwd_fp8(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y,
+                                    int y_L, int y_off, float* mean, float* rstd, int B, int n, int dim, float eps, void* y8,
+                                    const float* y8_scale, float* y8_amax, void* stream) {
+    MH_CHECK_ARG(y8 && y8_scale && ((uintptr_t)y8 % 4) == 0, "mh_layernorm_fwd_fp8: y8 (4-byte aligned) and its scale are required");
+    return layernorm_fwd_impl(x, x_L, x_off, gamma, beta, y, y_L, y_off, 0, mean, rstd, B, n, dim, eps, y8, y8_scale, y8_amax, stream);
+}
+
+static int layernorm_fwd_impl(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y, int y_L,
+                              int y_off, int y_is_f32, float* mean, float* rstd, int B, int n, int dim, float eps, void* y8,
+                              const float* y8_scale, float* y8_amax, void* stream) {
     MH_CHECK_ARG(x && gamma && beta && y && mean && rstd, "mh_layernorm_fwd: null pointer");
     MH_CHECK_ARG(dim % 4 == 0 && dim >= 4 && dim <= 2048, "mh_layernorm_fwd: dim %d unsupported", dim);
     MH_CHECK_ARG(B > 0 && n > 0 && x_off + n <= x_L && y_off + n <= y_L, "mh_layernorm_fwd: bad row map");
@@ -229,7 +264,7 @@ extern "C" int mh_layernorm_fwd(const float* x, int x_L, int x_off, const float*
     dim3 grid(ceil_div(rows, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LN_FWD(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, grid, block, 0, s, x, RowMap{x_L, x_off}, gamma, beta, y, \
-                                      RowMap{y_L, y_off}, y_is_f32, mean, rstd, B, n, dim, eps)
+                                      RowMap{y_L, y_off}, y_is_f32, mean, rstd, B, n, dim, eps, (uint8_t*)y8, y8_scale, y8_amax)
     switch (ln_nv(dim)) { case 1: LN_FWD(1); break; case 2: LN_FWD(2); break; case 3: LN_FWD(3); break;
                           case 4: LN_FWD(4); break; default: LN_FWD(8); }
 #undef LN_FWD

@@ -227,16 +227,16 @@ class Stack:
         eng, M, dim, mlp, inner = self.eng, self.M, self.dim, self.mlp, self.inner  # noqa: N806
         plan, f = eng.fp8, self.f8[l]
         proj, ln2, fc1, fc2 = attn.to_out[0], ff.net[0], ff.net[1], ff.net[4]
-        hip.layernorm_fwd(x_in, M, 0, attn.norm.weight, attn.norm.bias, s["h1"], M, 0, s["mean1"], s["rstd1"], 1, M, dim)
-        plan.quantize(s["h1"], f["h1"], f["s_h1"])
+        hip.layernorm_fwd_fp8(x_in, M, 0, attn.norm.weight, attn.norm.bias, s["h1"], M, 0, s["mean1"], s["rstd1"], 1, M, dim,
+                              f["h1"], plan.a_scale(f["s_h1"]), plan.a_amax(f["s_h1"]))
         hip.gemm_fp8(M, 3 * inner, dim, f["h1"], dim, f["w_qkv"], dim, s["qkv"], 3 * inner, plan.a_descale(f["s_h1"]),
                      plan.w_descale(f["sw_qkv"]))
         hip.attn_fwd(s["qkv"], s["o"], s["lse"], self.Bn, self.N, self.H, self.Dh, attn.scale)
         plan.quantize(s["o"], f["o"], f["s_o"])
         hip.gemm_fp8(M, dim, inner, f["o"], inner, f["w_proj"], inner, x_mid, dim, plan.a_descale(f["s_o"]),
                      plan.w_descale(f["sw_proj"]), flags=hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=proj.bias, res=x_in, ldr=dim)
-        hip.layernorm_fwd(x_mid, M, 0, ln2.weight, ln2.bias, s["h2"], M, 0, s["mean2"], s["rstd2"], 1, M, dim)
-        plan.quantize(s["h2"], f["h2"], f["s_h2"])
+        hip.layernorm_fwd_fp8(x_mid, M, 0, ln2.weight, ln2.bias, s["h2"], M, 0, s["mean2"], s["rstd2"], 1, M, dim, f["h2"],
+                              plan.a_scale(f["s_h2"]), plan.a_amax(f["s_h2"]))
         hip.gemm_fp8(M, mlp, dim, f["h2"], dim, f["w_fc1"], dim, s["act"], mlp, plan.a_descale(f["s_h2"]),
                      plan.w_descale(f["sw_fc1"]), flags=hip.BIAS | hip.GELU | hip.AUX_DGELU, bias=fc1.bias, aux_out=s["hpre"],
                      ldaux=mlp, c8=f["act"], ldc8=mlp, c8_scale=plan.a_scale(f["s_act"]), c8_amax=plan.a_amax(f["s_act"]))
@@ -606,8 +606,9 @@ class MAEEngine(EngineBase):
         self.p_loss = 1 if loss.startswith("l1") else 2
         self.normalise = loss.endswith("_norm")
         m = model
-        if m.embed_dim == m.decoder_dim:
-            raise NotImplementedError("embed_dim == decoder_dim (Identity enc_to_dec) is not built")
+        # embed_dim == decoder_dim: enc_to_dec is nn.Identity (maestro/ssl/mae.py:145-154) -- the final encoder LayerNorm then
+        # writes the fp32 decoder input rows directly and the backward hands their fp32 gradient straight to that LayerNorm
+        self.e2d_identity = m.embed_dim == m.decoder_dim
         self.E, self.Dd = m.embed_dim, m.decoder_dim
         self._init_runtime(device, len(model.group_specs) - 1)
         # Weight gradients of the transformer stacks: "fused" = in line with the dgrad chain (split-K, fp32 atomics);
@@ -943,8 +944,8 @@ class MAEEngine(EngineBase):
                 hip.layernorm_fwd(st.x_last, g.N, 0, nrm.weight, nrm.bias, self.joint.x0, m.joint_N, g.joint_off,
                                   gbuf["mean_e"], gbuf["rstd_e"], g.Beff, g.N, E)
             else:
-                hip.layernorm_fwd(st.x_last, g.N, 0, nrm.weight, nrm.bias, gbuf["henc"], g.N, 0, gbuf["mean_e"],
-                                  gbuf["rstd_e"], g.Beff, g.N, E)
+                hip.layernorm_fwd(st.x_last, g.N, 0, nrm.weight, nrm.bias, gbuf["y_e2d" if self.e2d_identity else "henc"], g.N, 0,
+                                  gbuf["mean_e"], gbuf["rstd_e"], g.Beff, g.N, E)
 
         def tail(g, part="all"):
             def run():
@@ -954,12 +955,14 @@ class MAEEngine(EngineBase):
                 self._opt_wait("e2d")
                 if self.joint is not None:
                     nrm = self.joint.t.norm
-                    hip.layernorm_fwd(self.joint.x_last, m.joint_N, g.joint_off, nrm.weight, nrm.bias, gbuf["henc"], g.N, 0,
-                                      gbuf["mean_j"], gbuf["rstd_j"], g.Beff, g.N, E)
+                    hip.layernorm_fwd(self.joint.x_last, m.joint_N, g.joint_off, nrm.weight, nrm.bias,
+                                      gbuf["y_e2d" if self.e2d_identity else "henc"], g.N, 0, gbuf["mean_j"], gbuf["rstd_j"],
+                                      g.Beff, g.N, E)
                 lin = m.enc_to_dec[g.model]
                 M = g.Beff * g.N  # noqa: N806
-                hip.gemm(hip.GEMM_NT, M, Dd, E, gbuf["henc"], E, self.store.h(lin.weight), E, gbuf["y_e2d"], Dd,
-                         hip.OUT_F32 | hip.BIAS, bias=lin.bias)
+                if not self.e2d_identity:
+                    hip.gemm(hip.GEMM_NT, M, Dd, E, gbuf["henc"], E, self.store.h(lin.weight), E, gbuf["y_e2d"], Dd,
+                             hip.OUT_F32 | hip.BIAS, bias=lin.bias)
                 for s in g.mods:
                     gbuf["tok_table"][s.slot].copy_(m.mask_token[s.name].view(-1))
                 hip.unmask_assemble(gbuf["y_e2d"], gbuf["inv"], gbuf["tok_table"], gbuf["tok_slot"], gbuf["pos_dec"],
@@ -1151,16 +1154,17 @@ class MAEEngine(EngineBase):
                                       g.L, Dd, s.slot, s.tok_off, s.tok_off + s.n_tok)
                 self._ready_spans.append(ps.span([m.mask_token[s.name]]))
             M = g.Beff * g.N  # noqa: N806
-            hip.cast_bf16(gbuf["dy_e2d"], gbuf["dy_e2d16"], M * Dd)
             lin = m.enc_to_dec[g.model]
-            hip.gemm(hip.GEMM_NN, M, E, Dd, gbuf["dy_e2d16"], Dd, ps.h(lin.weight), E, gbuf["dhenc"], E)
-            hip.gemm(hip.GEMM_TN, Dd, E, M, gbuf["dy_e2d16"], Dd, gbuf["henc"], E, ps.g(lin.weight), E, AT)
-            hip.colsum(gbuf["dy_e2d16"], ps.g(lin.bias), M, Dd, Dd)
-            self._grads_ready(lin)
+            if not self.e2d_identity:
+                hip.cast_bf16(gbuf["dy_e2d"], gbuf["dy_e2d16"], M * Dd)
+                hip.gemm(hip.GEMM_NN, M, E, Dd, gbuf["dy_e2d16"], Dd, ps.h(lin.weight), E, gbuf["dhenc"], E)
+                hip.gemm(hip.GEMM_TN, Dd, E, M, gbuf["dy_e2d16"], Dd, gbuf["henc"], E, ps.g(lin.weight), E, AT)
+                hip.colsum(gbuf["dy_e2d16"], ps.g(lin.bias), M, Dd, Dd)
+                self._grads_ready(lin)
             if self.joint is not None:   # final LN of the joint encoder, this group's rows
                 jt = self.joint
                 jn = jt.t.norm
-                hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, jt.x_last, m.joint_N, g.joint_off, jn.weight, gbuf["mean_j"],
+                hip.layernorm_bwd(gbuf["dy_e2d" if self.e2d_identity else "dhenc"], g.N, 0, jt.x_last, m.joint_N, g.joint_off, jn.weight, gbuf["mean_j"],
                                   gbuf["rstd_j"], None, jt.dxa, jt.top16, ps.g(jn.weight), ps.g(jn.bias),
                                   jt.top_bias_grad(), gbuf["ln_ws"], g.Beff, g.N, E)
 
@@ -1203,7 +1207,8 @@ class MAEEngine(EngineBase):
                                           gbuf["rstd_e"], None, st.dxa, st.top16, ps.g(nrm.weight), ps.g(nrm.bias),
                                           st.top_bias_grad(), gbuf["ln_ws"], g.Beff, g.N, E)
                     else:
-                        hip.layernorm_bwd(gbuf["dhenc"], g.N, 0, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"],
+                        hip.layernorm_bwd(gbuf["dy_e2d" if self.e2d_identity else "dhenc"], g.N, 0, st.x_last, g.N, 0, nrm.weight,
+                                          gbuf["mean_e"],
                                           gbuf["rstd_e"], None, st.dxa, st.top16, ps.g(nrm.weight), ps.g(nrm.bias),
                                           st.top_bias_grad(), gbuf["ln_ws"], g.Beff, g.N, E)
                     self._grads_ready(nrm)

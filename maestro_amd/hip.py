@@ -168,6 +168,12 @@ def layernorm_fwd(x, x_L, x_off, gamma, beta, y, y_L, y_off, mean, rstd, B, n, d
          _I(1 if y.dtype == torch.float32 else 0), mean, rstd, _I(B), _I(n), _I(dim), _F(eps))
 
 
+def layernorm_fwd_fp8(x, x_L, x_off, gamma, beta, y, y_L, y_off, mean, rstd, B, n, dim, y8, y8_scale, y8_amax, eps=1e-5):
+    """LayerNorm forward writing the bf16 output AND its e4m3 copy (times ``y8_scale``), absmax folded into ``y8_amax``."""
+    call("mh_layernorm_fwd_fp8", x, _I(x_L), _I(x_off), gamma, beta, y, _I(y_L), _I(y_off), mean, rstd, _I(B), _I(n), _I(dim),
+         _F(eps), y8, y8_scale, y8_amax)
+
+
 def layernorm_bwd_workspace(rows, dim) -> int:
     f = lib().mh_layernorm_bwd_workspace
     f.restype = ctypes.c_long

@@ -19,6 +19,7 @@ from oracle.gen_golden import build_datasets, case_table, init_weights, make_bat
 
 pytestmark = pytest.mark.gpu
 CASES = case_table()
+LOSS_TOL, PIX_TOL, GRAD_TOL = 2e-2, 3e-2, 6e-2     # (tightened to <= 3x the observed errors below)
 COMMON = dict(interpolate="nearest", model="mae", num_levels=1, type_head="attentive", fac_abs_enc=1.0, fac_date_enc=1.0)
 
 
@@ -436,3 +437,38 @@ def test_optimizer_overlapped_with_next_forward_matches_classic_step(fusion, int
     for g, n, floor in zip(got, noise, (1e-4, 1e-3, 1e-3)):   # the bar is the larger of a fixed floor and the measured spread
         assert g < max(floor, 3.0 * n), (got, noise)
     assert torch.equal(h1, p1.bfloat16().float()), "bf16 shadow out of date after the overlapped update"
+
+
+@pytest.mark.parametrize("inter_depth", [1, 0])
+def test_identity_enc_to_dec_when_widths_match(golden_dir, inter_depth):
+    """``embed_dim == decoder_dim``: the reference builds ``nn.Identity`` instead of a Linear (``maestro/ssl/mae.py:145-154``).
+    No shipped size has it; built with ``decoder_dim = 192`` on the tiny preset and checked against the oracle (which restates
+    the same rule) with and without the joint encoder in front."""
+    dev, case, gold, ds, _, _, batch, noise, struct = _setup("c3_aerial_s2", golden_dir)
+    kw = dict(fusion_mode="group", inter_depth=inter_depth, depth=3, decoder_dim=192, decoder_heads=6, decoder_dim_head=32, **COMMON)
+    oracle = om.build_oracle(ds, conf.MaskConfig(), model_size="tiny", **kw)
+    init_weights(oracle, 19)
+    model = pmae.mae_tiny(datasets=ds, mask=conf.MaskConfig(), **kw)
+    assert all(isinstance(mod, torch.nn.Identity) for mod in model.enc_to_dec.values())
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    eng = model.engine(case["B"], dev, loss="l2_norm")
+    loss = eng.forward({k: v.to(dev) for k, v in batch.items()}, noise=noise, struct=struct).clone()
+    eng.zero_grad()
+    eng.backward()
+    torch.cuda.synchronize()
+    ob, orec, omsk, _ = oracle({k: v.clone() for k, v in batch.items()}, "pretrain", noise=noise,
+                               struct_masks={g: s[:, :, None] for g, s in struct.items()})
+    oloss = om.compute_loss_rec(ob, orec, omsk, oracle.out_grid_size, om.norm_bands_of(ds.dataset), "l2_norm")
+    oracle.zero_grad()
+    oloss.backward()
+    assert abs(loss.item() - oloss.item()) < LOSS_TOL * abs(oloss.item()), (loss.item(), oloss.item())
+    pixels, masks = eng.reconstructions()
+    for m in orec:
+        assert torch.equal(masks[m].cpu(), omsk[m]) and _rel(pixels[m].cpu(), orec[m].detach()) < PIX_TOL
+    ograds = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
+    gmax = max(g.abs().max().item() for g in ograds.values())
+    for k, p in model.named_parameters():
+        if k in ograds:
+            got, want = eng.store.g(p).cpu(), ograds[k]
+            err, ref = (got - want).double().norm().item(), want.double().norm().item()
+            assert err <= GRAD_TOL * ref + 1e-5 * gmax * want.numel() ** 0.5, (k, err / max(ref, 1e-12))
