@@ -5,23 +5,39 @@
 //         the fp8 rate on CDNA4 (K = 128 per instruction, 2x the bf16 FLOP per clock; the plain fp8 16x16x32 form runs at the
 //         bf16 rate).  Per-TENSOR scaling: the quantisers (quant.hip) multiply by a power-of-two scale kept on the device, the
 //         epilogue multiplies the accumulators by the two descale factors.
-//   tile  256 x 256 x 128 per 512-thread workgroup (8 waves, 2 x 4, 128 x 64 per wave = 8 x 4 MFMA tiles), both operands
+//   tile  256 x 256 x 128 per 512-thread workgroup (8 waves, 2 x 4, 128 x 64 per wave = 8 x 4 MFMA tiles) or 128 x 128 x 128
+//         per 256-thread workgroup (small problems, two workgroups per CU), both operands
 //         K-minor ("NT": the dgrad uses a transposed fp8 weight shadow instead of a K-major read), so per output FLOP the
 //         kernel moves HALF the operand bytes of the bf16 kernels through L2 -> LDS -- the path that bounds those kernels.
-//   LDS   2-stage ring of (A 32 KiB + B 32 KiB), operands by LDS-DMA (buffer_load ... lds, 8 one-KiB pieces per wave and K
+//   LDS   2-stage ring of (A + B tile: 64 KiB / 32 KiB), operands by LDS-DMA (buffer_load ... lds, 8 one-KiB pieces per wave and K
 //         step), one raw s_barrier per K step; 128-byte rows, 16-byte chunk position p holds source chunk p ^ (row & 7)
 //         (swizzle on the per-lane SOURCE offset and again on the fragment reads: conflict-free ds_read_b128).
 //   operand map (checked with exact integer data, tests/test_fp8_gpu.py): lane l holds row (l & 15), K block (l >> 4) of 32
 //         consecutive bytes; C / D as every 16 x 16 MFMA: column l & 15, rows 4 (l >> 4) + r.
 #include "gemm_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BK8 = 128, S8 = 2, NW8 = 8, NT8 = 512;
-constexpr int TILE8_BYTES = 256 * BK8;              // one operand tile: 256 rows x 128 B = 32 KiB
-constexpr int STAGE8_BYTES = 2 * TILE8_BYTES;       // A + B
-constexpr int LDS8_BYTES = S8 * STAGE8_BYTES;       // 128 KiB (also the epilogue staging: 8 waves x 32 x 68 floats = 68 KiB)
-constexpr int PP8 = TILE8_BYTES / 1024 / NW8;       // 4 one-KiB pieces per wave, operand and K step
+constexpr int BK8 = 128, S8 = 2;
+
+// Tile geometry: WM x WN waves, each a (16 MT) x 64 accumulator block.
+//   <2,4,8> 256 x 256, 512 threads, 128 KiB ring, one workgroup per CU: the large decoder / joint problems
+//   <2,2,4> 128 x 128, 256 threads,  64 KiB ring, TWO workgroups per CU (one's epilogue overlaps the other's main loop): the
+//           per-group encoder problems of C5 (M = 512 .. 4608 token rows: 54 .. 216 tiles of 256 x 256 would leave most of the
+//           256 CUs idle).  At one byte per element this tile moves the same operand bytes per FLOP as the bf16 256 x 256 tile.
+template <int WM_, int WN_, int MT_>
+struct Tile8 {
+    static constexpr int WM = WM_, WN = WN_, MT = MT_;
+    static constexpr int BM = 16 * MT * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
+    static constexpr int A_BYTES = BM * BK8, B_BYTES = BN * BK8, STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = S8 * STAGE_BYTES;
+    static constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;   // one-KiB DMA pieces per wave and K step
+    static constexpr int MIN_WAVES = NT >= 512 ? 2 : 2;                        // waves per SIMD the register budget must allow
+    static_assert(PA * NW * 1024 == A_BYTES && PB * NW * 1024 == B_BYTES, "pieces must divide evenly over the waves");
+    static_assert(LDS_BYTES >= NW * 32 * 68 * 4, "the ring doubles as epilogue staging");
+};
+typedef Tile8<2, 4, 8> T8_256;
+typedef Tile8<2, 2, 4> T8_128;
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((address_space(3))) void lds_void8;
@@ -38,9 +54,11 @@ __device__ __forceinline__ i32x8 read_frag8(const unsigned char* img, int rc0) {
 }
 
 // A_E5M2: the A operand (activations / gradients, the MFMA's second source here) is e5m2 instead of e4m3
-template <bool A_E5M2>
-__global__ __launch_bounds__(NT8, 2) void gemm_fp8_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS8_BYTES];   // the ONLY LDS object
+// (Body as a __device__ function template, the kernel a thin wrapper: the host pass of hipcc 7.2 does not emit the launch stub
+// of a kernel template whose own body holds the LDS-DMA builtin inside a lambda.)
+template <class T, bool A_E5M2>
+__device__ __forceinline__ void gemm_fp8_body(const GemmParams& p, unsigned char* smem) {
+    constexpr int MT = T::MT, NW = T::NW, PA = T::PA, PB = T::PB;
     const int nwg = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nwg);
     constexpr int GROUP_M = 4;
@@ -49,69 +67,86 @@ __global__ __launch_bounds__(NT8, 2) void gemm_fp8_kernel(GemmParams p) {
     const int first_m = group * GROUP_M;
     const int gsz = min(p.tiles_m - first_m, GROUP_M);
     const int tile_m = first_m + in_group % gsz, tile_n = in_group / gsz;
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int m0 = tile_m * T::BM, n0 = tile_n * T::BN;
     const int nk = p.K / BK8;
 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
-    const int wm = (w >> 2) * 128, wn = (w & 3) * 64;
+    const int wm = (w / T::WN) * (16 * MT), wn = (w % T::WN) * 64;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, (short)0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, (short)0, (int)p.b_bytes, 0x00020000);
-    int va[PP8], vb[PP8];   // per-lane source byte offsets of this wave's pieces (piece = 8 rows x 128 B), k = 0
+    int va[PA], vb[PB];   // per-lane source byte offsets of this wave's pieces (piece = 8 rows x 128 B), k = 0
 #pragma unroll
-    for (int h = 0; h < PP8; ++h) {
-        const int row = (w + NW8 * h) * 8 + (l >> 3), pos = l & 7;
+    for (int h = 0; h < PA; ++h) {
+        const int row = (w + NW * h) * 8 + (l >> 3), pos = l & 7;
         va[h] = (m0 + row) * p.lda + ((pos ^ (row & 7)) << 4);
+    }
+#pragma unroll
+    for (int h = 0; h < PB; ++h) {
+        const int row = (w + NW * h) * 8 + (l >> 3), pos = l & 7;
         vb[h] = (n0 + row) * p.ldb + ((pos ^ (row & 7)) << 4);
     }
     auto issue = [&](int t) {
-        unsigned char* slot = smem + (t % S8) * STAGE8_BYTES;
+        unsigned char* slot = smem + (t % S8) * T::STAGE_BYTES;
 #pragma unroll
-        for (int h = 0; h < PP8; ++h)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void8*)(slot + (w + NW8 * h) * 1024), 16, va[h], t * BK8, 0, 0);
+        for (int h = 0; h < PA; ++h)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void8*)(slot + (w + NW * h) * 1024), 16, va[h], t * BK8, 0, 0);
 #pragma unroll
-        for (int h = 0; h < PP8; ++h)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void8*)(slot + TILE8_BYTES + (w + NW8 * h) * 1024), 16, vb[h],
+        for (int h = 0; h < PB; ++h)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void8*)(slot + T::A_BYTES + (w + NW * h) * 1024), 16, vb[h],
                                                      t * BK8, 0, 0);
     };
 
-    f32x4 acc[4][8];   // [j (n tile)][i (m tile)]
+    f32x4 acc[4][MT];   // [j (n tile)][i (m tile)]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     issue(0);
     for (int t = 0; t < nk; ++t) {
         wait_vm8<0>();                    // my pieces of step t (the only DMA in flight) have landed
         __builtin_amdgcn_s_barrier();     // everybody's have; step t-1 has been read by everybody -> its slot can be refilled
-        const unsigned char* ta = smem + (t % S8) * STAGE8_BYTES;
-        const unsigned char* tb = ta + TILE8_BYTES;
+        const unsigned char* ta = smem + (t % S8) * T::STAGE_BYTES;
+        const unsigned char* tb = ta + T::A_BYTES;
         i32x8 fb[4], fa[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = read_frag8(tb, wn + 16 * j);
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[i] = read_frag8(ta, wm + 16 * i);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < nk) issue(t + 1);     // streams under this step's 32 MFMAs (32 x 32 cycles per wave, two waves per SIMD)
+        if (t + 1 < nk) issue(t + 1);     // streams under this step's MFMAs (32 cycles each, two waves per SIMD)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int half = 0; half < MT / 4; ++half) {     // four m-tiles at a time: A fragments are 8 registers each
+            if (half > 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i], acc[j][i], 0, A_E5M2 ? 1 : 0, 0,
-                                                                             0x7f7f7f7f, 0, 0x7f7f7f7f);
+                for (int i = 0; i < 4; ++i) fa[i] = read_frag8(ta, wm + 64 * half + 16 * i);
+            }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = read_frag8(ta, wm + 64 + 16 * i);   // second half of the wave's rows
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[j][4 + i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i], acc[j][4 + i], 0, A_E5M2 ? 1 : 0, 0,
-                                                                                 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                for (int j = 0; j < 4; ++j)
+                    acc[j][4 * half + i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                        fb[j], fa[i], acc[j][4 * half + i], 0, A_E5M2 ? 1 : 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
     }
     __builtin_amdgcn_s_barrier();   // all reads of the ring are done: reuse it as epilogue staging
     float* st = reinterpret_cast<float*>(smem) + w * (32 * 68);
-    gemm_epilogue_store<8>(p, acc, st, m0 + wm, n0 + wn);
+    gemm_epilogue_store<MT>(p, acc, st, m0 + wm, n0 + wn);
+}
+
+template <class T, bool A_E5M2>
+__global__ __launch_bounds__(T::NT, 2) void gemm_fp8_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[T::LDS_BYTES];   // the ONLY LDS object
+    gemm_fp8_body<T, A_E5M2>(p, smem);
+}
+
+template <class T>
+void launch_fp8(GemmParams& p, int a_format, hipStream_t s) {
+    p.tiles_m = ceil_div(p.M, T::BM); p.tiles_n = ceil_div(p.N, T::BN);
+    dim3 grid(p.tiles_m * p.tiles_n), block(T::NT);
+    if (a_format == MH_FP8_E5M2) hipLaunchKernelGGL((gemm_fp8_kernel<T, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_fp8_kernel<T, false>), grid, block, 0, s, p);
 }
 
 }  // namespace
@@ -142,16 +177,20 @@ extern "C" int mh_gemm_fp8(int M, int N, int K, const void* A8, int lda, int a_f
     p.A = (const bf16_t*)A8; p.B = (const bf16_t*)B8; p.C = C;
     p.bias = bias; p.res = res; p.aux_in = (const bf16_t*)aux_in; p.aux_out = (bf16_t*)aux_out; p.colsum = colsum;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.flags = flags;
-    p.tiles_m = ceil_div(M, 256); p.tiles_n = ceil_div(N, 256); p.k_per_split = K; p.fast = 1;
+    p.k_per_split = K; p.fast = 1;
     const long a_ext = (long)(M - 1) * lda + K, b_ext = (long)(N - 1) * ldb + K;   // bytes: rows beyond M / N read as zero
-    MH_CHECK_ARG((long)p.tiles_m * 256 * lda + 65536 < (1L << 31) && (long)p.tiles_n * 256 * ldb + 65536 < (1L << 31),
+    MH_CHECK_ARG((long)ceil_div(M, 256) * 256 * lda + 65536 < (1L << 31) && (long)ceil_div(N, 256) * 256 * ldb + 65536 < (1L << 31),
                  "mh_gemm_fp8: operand beyond the 2 GiB buffer-descriptor range");
     p.a_bytes = (unsigned)a_ext; p.b_bytes = (unsigned)b_ext;
     p.descale_a = descale_a; p.descale_b = descale_b;
     p.c8 = (uint8_t*)c8; p.c8_scale = c8_scale; p.c8_amax = c8_amax; p.ldc8 = ldc8;
-    dim3 grid(p.tiles_m * p.tiles_n), block(NT8);
-    if (a_format == MH_FP8_E5M2) hipLaunchKernelGGL(gemm_fp8_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(gemm_fp8_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
+    // 256 x 256 tiles when they fill the 256 CUs for at least ~1.5 rounds, else 128 x 128 (two workgroups per CU).
+    // MH_FP8_TILE=128|256 forces one (experiments).
+    const long tiles256 = (long)ceil_div(M, 256) * ceil_div(N, 256);
+    const char* force = getenv("MH_FP8_TILE");
+    const bool big = force ? force[0] == '2' : tiles256 >= 384;
+    if (big) launch_fp8<T8_256>(p, a_format, (hipStream_t)stream);
+    else launch_fp8<T8_128>(p, a_format, (hipStream_t)stream);
     MH_LAUNCH_CHECK();
     return 0;
 }
