@@ -390,13 +390,15 @@ def main() -> None:
                 out["roofline_fp8_kernel"] = {"bound": "mfma", "kernel": "gemm_fp8_kernel", "achieved": round(ach, 1),
                                               "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP8_PEAK_TFLOPS, 4),
                                               "launches": timer.count["gemm_fp8_kernel"]}
-            traffic_file = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+            traffic_file = next((f for f in (os.path.join(ROOT, "profiles", f"r{r:02d}_hbm_traffic.json") for r in (9, 8, 7, 6, 5, 4, 3, 2, 1))
+                                 if os.path.exists(f)), "")
             # PMC passes are separate runs (rocprofv3 --pmc) of the DEFAULT workload: the committed summary applies to it only
             if os.path.exists(traffic_file) and args.phase == "pretrain" and args.config == "c3" and args.batch == 32:
                 kern = json.load(open(traffic_file))["kernels"].get(out["roofline"]["kernel"])
                 if kern:
                     out["roofline"]["traffic"] = kern["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                    out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(traffic_file)} (rocprofv3 --pmc FETCH_SIZE / "
+                                                         "WRITE_SIZE passes of this command)")
                 whole = json.load(open(traffic_file)).get("hbm_bytes_per_step")
                 if whole:   # every kernel's PMC bytes per launch x launches per step: the step's second bound next to mfma_frac
                     out["whole_step"]["hbm_gb_per_step"] = round(whole / 1e9, 1)

@@ -184,11 +184,14 @@ extern "C" int mh_gemm_fp8(int M, int N, int K, const void* A8, int lda, int a_f
     p.a_bytes = (unsigned)a_ext; p.b_bytes = (unsigned)b_ext;
     p.descale_a = descale_a; p.descale_b = descale_b;
     p.c8 = (uint8_t*)c8; p.c8_scale = c8_scale; p.c8_amax = c8_amax; p.ldc8 = ldc8;
-    // 256 x 256 tiles when they fill the 256 CUs for at least ~1.5 rounds, else 128 x 128 (two workgroups per CU).
+    // 128 x 128 tiles (two workgroups per CU: one's epilogue under the other's main loop, and room for other streams' kernels
+    // beside it) unless the problem is long in K and fills the chip with 256 x 256 tiles for several rounds -- measured
+    // (scripts/bench_fp8_gemm.py): 128^2 is as fast or faster on every shape of the C5 / C3 steps (e.g. 8192 x 768 x 3072:
+    // 1403 vs 855 TFLOP/s; 32768 x 3072 x 512: 1090 vs 1061), 256^2 wins at 16384 x 4096 x 4096 (2140 vs 1796).
     // MH_FP8_TILE=128|256 forces one (experiments).
     const long tiles256 = (long)ceil_div(M, 256) * ceil_div(N, 256);
     const char* force = getenv("MH_FP8_TILE");
-    const bool big = force ? force[0] == '2' : tiles256 >= 384;
+    const bool big = force ? force[0] == '2' : (tiles256 >= 768 && K >= 2048);
     if (big) launch_fp8<T8_256>(p, a_format, (hipStream_t)stream);
     else launch_fp8<T8_128>(p, a_format, (hipStream_t)stream);
     MH_LAUNCH_CHECK();

@@ -29,6 +29,7 @@ class Fp8Plan:
         self._w_jobs, self._n_act = [], 0
         self.wsc = self.asc = None
         self._wbatch = None
+        self._w_ready = False
         self._abatch: dict = {}
 
     # ---- registration (while the engine allocates its buffers)
@@ -54,13 +55,22 @@ class Fp8Plan:
             self._wbatch = hip.QuantBatch(self._w_jobs, self.wsc, self.device)
 
     # ---- per step
-    def refresh_weights(self) -> None:
-        """absmax -> scales -> e4m3 shadows of every registered weight (call after the fp32 masters changed)."""
+    def refresh_weights(self, exact: bool = False) -> None:
+        """e4m3 shadows of every registered weight (call after the fp32 masters changed).  The first call (and ``exact``:
+        parameters replaced wholesale, e.g. a checkpoint load) runs ``absmax -> scales -> cast`` (three passes); afterwards
+        weights move by a learning-rate step at a time, so ONE pass casts with the scales derived from the previous call's
+        absmax and records the new absmax (delayed scaling with one binade of head-room; 5 instead of 9 bytes per weight)."""
         if self._wbatch is None:
             return
-        self._wbatch.launch(0)
-        self.wsc.update(fmt=hip.FP8_E4M3, margin=1)
-        self._wbatch.launch(1)
+        if exact or not self._w_ready:
+            self._wbatch.launch(0)
+            self.wsc.update(fmt=hip.FP8_E4M3, margin=1)
+            self._wbatch.launch(1)
+            self._wbatch.launch(0)       # leave this state's absmax behind for the next (one-pass) call
+            self._w_ready = True
+        else:
+            self.wsc.update(fmt=hip.FP8_E4M3, margin=1)
+            self._wbatch.launch(2)
 
     def quantize(self, src: torch.Tensor, dst: torch.Tensor, slot: int) -> None:
         """Activation cast with the current scale of ``slot`` + absmax for the next step (delayed scaling)."""

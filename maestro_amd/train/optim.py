@@ -55,6 +55,11 @@ class FusedAdamW:
     def step(self, lr: float | None = None, grad_scale: float = 1.0, split: int = 0, between=None) -> None:
         """``split`` / ``between``: update ``[split, hi)`` first, call ``between()`` (e.g. wait for the last gradient bucket),
         then update ``[lo, split)`` -- the data-parallel loop hides its exposed all-reduce under the first launch."""
+        import os
+        import torch
+        roctx = os.environ.get("MAESTRO_ROCTX", "0") == "1"
+        if roctx:
+            torch.cuda.nvtx.range_push("maestro:adamw")
         st = self.engine.store
         self.t += 1
         lr = self.lr if lr is None else lr
@@ -67,7 +72,9 @@ class FusedAdamW:
                 hip.adamw(st.flat[a:b], st.grad[a:b], self.m[a - lo: b - lo], self.v[a - lo: b - lo], st.half[a:b], b - a, lr,
                           self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
         st.mark_synced()               # bf16 shadows were refreshed by the kernel itself
-        self.engine._pack_conv_weights()  # patch-embed weights live in a K-padded bf16 layout
+        self.engine._pack_conv_weights()  # patch-embed weights live in a K-padded bf16 layout (+ the e4m3 shadows in fp8 mode)
+        if roctx:
+            torch.cuda.nvtx.range_pop()
 
     def state_dict(self) -> dict:
         return {"m": self.m, "v": self.v, "t": self.t, "lr": self.lr}

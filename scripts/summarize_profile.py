@@ -27,7 +27,7 @@ def short(name):
     m = re.match(r"gemm_kernel<(\w+), (\w+)>", name)
     if m:
         return f"gemm_kernel<{_LAYOUT[m.groups()]}>"
-    m = re.match(r"gemm_dma_kernel<Tile<([\d, ]+)>, (\w+), (\w+)>", name)
+    m = re.match(r"gemm_dma_kernel<Tile<([\d, ]+)>, (\w+), (\w+)(?:, \w+)?>", name)   # (+ the STAGGER flag since round 2)
     if m:
         return f"gemm_dma_kernel<{_TILE[m.group(1)]},{_LAYOUT[(m.group(2), m.group(3))]}>"
     if name.startswith("gemm_dma_grouped_tn_kernel"):

@@ -1,11 +1,13 @@
 """End-to-end GPU parity of the HIP engine: forward, masks, loss and every parameter gradient vs the oracle and vs
 the REFERENCE's golden vectors (tests/golden/*.npz), same weights, same inputs, same injected RNG draws.
 
-Tolerances (bf16 MFMA GEMMs/attention with fp32 accumulation and fp32 residual stream vs an fp32 CPU oracle):
+Tolerances (bf16 MFMA GEMMs/attention with fp32 accumulation and fp32 residual stream vs an fp32 CPU oracle), set to <= 3x
+the worst error observed over all golden cases on MI355X (round 2, gpurun_out/observed_tiny.jsonl: loss 9.9e-4, pixels_rec
+4.4e-3, worst parameter gradient 1.18e-2; l1 losses 1.08e-2):
   mask indices ............ bit-exact
-  loss .................... |d| <= 2e-2 * |loss|
-  pixels_rec .............. relative L2 error <= 3e-2 per modality
-  parameter gradients ..... relative L2 error <= 6e-2 per parameter (plus an absolute floor for ~zero grads)
+  loss .................... |d| <= 3e-3 * |loss|
+  pixels_rec .............. relative L2 error <= 1.3e-2 per modality
+  parameter gradients ..... relative L2 error <= 3.5e-2 per parameter (plus an absolute floor for ~zero grads)
 """
 
 import numpy as np
@@ -19,7 +21,7 @@ from oracle.gen_golden import build_datasets, case_table, init_weights, make_bat
 
 pytestmark = pytest.mark.gpu
 CASES = case_table()
-LOSS_TOL, PIX_TOL, GRAD_TOL = 2e-2, 3e-2, 6e-2     # (tightened to <= 3x the observed errors below)
+LOSS_TOL, PIX_TOL, GRAD_TOL = 3e-3, 1.3e-2, 3.5e-2
 COMMON = dict(interpolate="nearest", model="mae", num_levels=1, type_head="attentive", fac_abs_enc=1.0, fac_date_enc=1.0)
 
 
@@ -78,13 +80,13 @@ def test_engine_matches_oracle_and_reference(golden_dir, name, wgrad, observed):
         ref_tok = np.unpackbits(gold[f"mask_tok/{m}"], axis=2)[:, :, : tok.shape[2]].astype(bool)
         assert np.array_equal(tok, ref_tok), f"{m}: mask indices differ from the reference"
         observed(f"tiny/{name}/{wgrad}", f"pixels/{m}", _rel(pixels[m].cpu(), orec[m].detach()))
-        assert _rel(pixels[m].cpu(), orec[m].detach()) < 3e-2, (m, _rel(pixels[m].cpu(), orec[m].detach()))
+        assert _rel(pixels[m].cpu(), orec[m].detach()) < PIX_TOL, (m, _rel(pixels[m].cpu(), orec[m].detach()))
         if group_of[m] not in multi:  # reference value independent of its implementation-defined tie order
-            assert _rel(pixels[m].cpu(), torch.from_numpy(gold[f"pixels_rec/{m}"])) < 3e-2
+            assert _rel(pixels[m].cpu(), torch.from_numpy(gold[f"pixels_rec/{m}"])) < PIX_TOL
     observed(f"tiny/{name}/{wgrad}", "loss", abs(loss.item() - oloss.item()) / abs(oloss.item()))
-    assert abs(loss.item() - oloss.item()) < 2e-2 * abs(oloss.item()), (loss.item(), oloss.item())
+    assert abs(loss.item() - oloss.item()) < LOSS_TOL * abs(oloss.item()), (loss.item(), oloss.item())
     if not multi:
-        assert abs(loss.item() - float(gold["loss_l2_norm"])) < 2e-2 * abs(float(gold["loss_l2_norm"]))
+        assert abs(loss.item() - float(gold["loss_l2_norm"])) < LOSS_TOL * abs(float(gold["loss_l2_norm"]))
 
     ograds = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
     worst = (0.0, None)
@@ -95,7 +97,7 @@ def test_engine_matches_oracle_and_reference(golden_dir, name, wgrad, observed):
         got, want = eng.store.g(p).cpu(), ograds[k]
         err = (got - want).double().norm().item()
         ref = want.double().norm().item()
-        ok = err <= 6e-2 * ref + 1e-3 * gmax * want.numel() ** 0.5 * 1e-2
+        ok = err <= GRAD_TOL * ref + 1e-3 * gmax * want.numel() ** 0.5 * 1e-2
         if err / max(ref, 1e-12) > worst[0]:
             worst = (err / max(ref, 1e-12), k)
         assert ok, f"{k}: grad rel err {err / max(ref, 1e-12):.3e} (|ref|={ref:.3e})"
@@ -110,7 +112,7 @@ def test_loss_variants(golden_dir, loss, observed):
     eng = model.engine(case["B"], dev, loss=loss)
     out = eng.forward({k: v.to(dev) for k, v in batch.items()}, noise=noise, struct=struct)
     want = float(gold[f"loss_{loss}"])
-    assert abs(out.item() - want) < 2e-2 * abs(want), (out.item(), want)
+    assert abs(out.item() - want) < LOSS_TOL * abs(want), (out.item(), want)
     eng.zero_grad()
     eng.backward()
     ob = {k: v.clone() for k, v in batch.items()}
@@ -118,9 +120,9 @@ def test_loss_variants(golden_dir, loss, observed):
     oracle.zero_grad()
     om.compute_loss_rec(ob, orec, omsk, oracle.out_grid_size, om.norm_bands_of(ds.dataset), loss).backward()
     ograds = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
-    # l1: d|x| = sign(x) flips for the few elements whose bf16 reconstruction lands on the other side of the target,
-    # so the tolerance is looser than for l2 (still a relative L2 error per parameter)
-    tol = 0.15 if loss.startswith("l1") else 0.06
+    # (l1: d|x| = sign(x) flips for the few elements whose bf16 reconstruction lands on the other side of the target; the
+    # observed relative L2 errors are nevertheless the same as for l2: 1.0e-2 .. 1.1e-2)
+    tol = GRAD_TOL
     gmax = max(g.abs().max().item() for g in ograds.values())
     worst = 0.0
     for k, p in model.named_parameters():
@@ -187,7 +189,7 @@ def test_input_resize_staging_matches_oracle(golden_dir, interpolate):
     ob = {k: v.clone() for k, v in small.items()}
     ob, orec, omsk, _ = oracle(ob, "pretrain", noise=noise, struct_masks={g: s[:, :, None] for g, s in struct.items()})
     oloss = om.compute_loss_rec(ob, orec, omsk, oracle.out_grid_size, om.norm_bands_of(ds.dataset), "l2_norm")
-    assert abs(loss.item() - oloss.item()) < 2e-2 * abs(oloss.item())
+    assert abs(loss.item() - oloss.item()) < LOSS_TOL * abs(oloss.item())
     returned = eng.returned_batch({k: v.to(dev) for k, v in small.items()})
     assert (returned["aerial"].cpu() - ob["aerial"]).abs().max() < 2e-6 and returned["aerial"].shape[-1] == 64
 
@@ -309,7 +311,7 @@ def test_log_tensors_match_reference(golden_dir, name):
                 if group_of[mod_name] in multi:
                     continue             # reconstruction depends on the reference's tie order there
                 err = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-12)
-                assert err < 3e-2, (key, err)
+                assert err < PIX_TOL, (key, err)
             else:
                 np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6, err_msg=key)
             seen += 1
