@@ -180,10 +180,6 @@ int mh_colsum_batched(const MhColsumJob* jobs_device, int n_jobs, const uint64_t
  * qkv: bf16 [B, N, 3, H, D] (= to_qkv output, chunk(3) then 'b n (h d) -> b h n d'); out: bf16 [B, N, H*D];
  * lse: f32 [B, H, N] (natural-log sum-exp of the scaled scores, saved for the backward).  D in {32, 64}. */
 int mh_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, void* stream);
-/* The same with an OCP e4m3 copy of the output (times *out8_scale; max |out| folded into *out8_amax, optional): the A
- * operand of the out-projection mh_gemm_fp8 in the fp8 path. */
-int mh_attn_fwd_fp8(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, void* out8,
-                    const float* out8_scale, float* out8_amax, void* stream);
 /* dqkv bf16 [B,N,3,H,D] from dout bf16 [B,N,H*D]; delta: f32 workspace [B,H,N]. */
 int mh_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                 int B, int N, int H, int D, float scale, void* stream);

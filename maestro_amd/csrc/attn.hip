@@ -8,7 +8,8 @@
 //   dK/dV kernel keeps the KEY on the lane:             S[q][key] = Q . K^T,  dV^T[d][key] = dO^T . P,  dK^T = Q^T . dS
 // K/V (or Q/dO) tiles of 64 rows are staged in LDS twice when needed: a "row image" read by ds_read_b128 and a
 // "transpose image" read by ds_read_b64_tr_b16 (hardware transpose), both XOR-swizzled to be bank-conflict free.
-#include "gemm_common.hpp"
+#include "common.hpp"
+#include "../../include/maestro_hip.h"
 #include <type_traits>
 
 namespace {
@@ -95,9 +96,7 @@ __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_ex
 // =============================================================================================== forward
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                       float* __restrict__ lse, int N, int H, float scale,
-                                                       uint8_t* __restrict__ out8, const float* __restrict__ out8_scale,
-                                                       float* __restrict__ out8_amax) {
+                                                       float* __restrict__ lse, int N, int H, float scale) {
     constexpr int KS = D / 32, DT = D / 16, TB = 64 * D * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TB];  // K row image | V transpose image
     unsigned char* k_img = smem;
@@ -215,8 +214,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const int nfull = N / 64;
     for (int it = 0; it < nfull; ++it) kv_tile(it, std::false_type{});
     if (nfull < ntile) kv_tile(nfull, std::true_type{});
-    const float s8 = out8 ? *out8_scale : 0.f;
-    float amax8 = 0.f;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + 16 * qt + lq;
@@ -225,30 +222,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         lt += __shfl_xor(lt, 32, 64);
         if (q >= N) continue;
         const float inv = 1.f / lt;
-        const size_t orow_off = ((size_t)b * N + q) * H * D + (size_t)h * D;
-        bf16_t* orow = out + orow_off;
+        bf16_t* orow = out + ((size_t)b * N + q) * H * D + (size_t)h * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const f32x4 v = o[qt][dt] * inv;
             u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             *reinterpret_cast<u32x2*>(orow + 16 * dt + 4 * g) = pk;
-            if (out8) {    // fp8 path: the e4m3 copy the out-projection GEMM reads (times *out8_scale) + its absmax
-                f32x4 q8;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    amax8 = fmaxf(amax8, fabsf(v[e]));
-                    q8[e] = fminf(fmaxf(v[e] * s8, -448.f), 448.f);
-                }
-                int a = __builtin_amdgcn_cvt_pk_fp8_f32(q8[0], q8[1], 0, false);
-                a = __builtin_amdgcn_cvt_pk_fp8_f32(q8[2], q8[3], a, true);
-                *reinterpret_cast<uint32_t*>(out8 + orow_off + 16 * dt + 4 * g) = (uint32_t)a;
-            }
         }
         if (g == 0) lse[((size_t)b * H + h) * N + q] = m[qt] * scale + logf(lt);  // m is a raw-score max
-    }
-    if (out8 && out8_amax) {
-        amax8 = wave_max(amax8);
-        if (l == 0 && amax8 > 0.f) atomic_max_pos(out8_amax, amax8);
     }
 }
 
@@ -529,26 +510,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 
 }  // namespace
 
-static int attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, void* out8,
-                         const float* out8_scale, float* out8_amax, void* stream) {
+extern "C" int mh_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, void* stream) {
     MH_CHECK_ARG(qkv && out && lse, "mh_attn_fwd: null pointer");
     MH_CHECK_ARG(B > 0 && N > 0 && H > 0 && (D == 32 || D == 64), "mh_attn_fwd: unsupported shape B=%d N=%d H=%d D=%d", B, N, H, D);
     MH_CHECK_ARG(H <= 65535 && B <= 65535, "mh_attn_fwd: grid limit");
     dim3 grid(ceil_div(N, 128) * H * B), block(256);
-    if (D == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale, (uint8_t*)out8, out8_scale, out8_amax);
-    else hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale, (uint8_t*)out8, out8_scale, out8_amax);
+    if (D == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
+    else hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
     MH_LAUNCH_CHECK();
     return 0;
-}
-
-extern "C" int mh_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, void* stream) {
-    return attn_fwd_impl(qkv, out, lse, B, N, H, D, scale, nullptr, nullptr, nullptr, stream);
-}
-
-extern "C" int mh_attn_fwd_fp8(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, void* out8,
-                               const float* out8_scale, float* out8_amax, void* stream) {
-    MH_CHECK_ARG(out8 && out8_scale && ((uintptr_t)out8 % 4) == 0, "mh_attn_fwd_fp8: out8 (4-byte aligned) and its scale are required");
-    return attn_fwd_impl(qkv, out, lse, B, N, H, D, scale, out8, out8_scale, out8_amax, stream);
 }
 
 extern "C" int mh_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,

@@ -233,16 +233,6 @@ def attn_fwd(qkv, out, lse, B, N, H, D, scale):
     call("mh_attn_fwd", qkv, out, lse, _I(B), _I(N), _I(H), _I(D), _F(scale))
 
 
-def attn_fwd_fp8(qkv, out, lse, B, N, H, D, scale, out8, out8_scale, out8_amax):
-    ev = None
-    if _timer is not None:
-        ev = _timer.record("attn_fwd", 4.0 * B * H * N * N * D, (B, N, H, D))
-        ev[0].record()
-    call("mh_attn_fwd_fp8", qkv, out, lse, _I(B), _I(N), _I(H), _I(D), _F(scale), out8, out8_scale, out8_amax)
-    if ev is not None:
-        ev[1].record()
-
-
 def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):
     call("mh_attn_bwd", qkv, out, dout, lse, delta, dqkv, _I(B), _I(N), _I(H), _I(D), _F(scale))
 

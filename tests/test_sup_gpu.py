@@ -2,9 +2,9 @@
 vectors (tests/golden/sup_*.npz), same weights, inputs and targets.
 
 Tolerances (bf16 GEMMs / attention with fp32 accumulation vs the fp32 CPU oracle):
-  loss_pred ............... |d| <= 2e-2 * |loss|
-  logits .................. relative L2 error <= 3e-2 per target
-  parameter gradients ..... relative L2 error <= 8e-2 per parameter (plus an absolute floor for ~zero grads);
+  loss_pred ............... |d| <= 1.2e-3 * |loss|
+  logits .................. relative L2 error <= 1.6e-2 per target
+  parameter gradients ..... relative L2 error <= 4.2e-2 per parameter (plus an absolute floor for ~zero grads);
                             probe: every non-head gradient is exactly zero (features detached, head.py:17-25)
 """
 
@@ -18,7 +18,7 @@ from oracle import heads as oh
 from tests.test_oracle_sup import CASES, build_sup_case
 
 pytestmark = pytest.mark.gpu
-LOSS_TOL = 2e-2
+LOSS_TOL, LOGIT_TOL, GRAD_TOL = 1.2e-3, 1.6e-2, 4.2e-2    # <= 3x observed on MI355X (round 2): 4.1e-4, 5.3e-3, 1.4e-2
 
 
 def _rel(a, b):
@@ -67,10 +67,10 @@ def test_supervised_engine_matches_oracle_and_reference(golden_dir, name, phase,
     for t in ologits:
         assert logits[t].shape == ologits[t].shape
         observed(f"sup/{name}/{phase}", f"logits/{t}", _rel(logits[t].cpu(), ologits[t].detach()))
-        assert _rel(logits[t].cpu(), ologits[t].detach()) < 3e-2, (t, _rel(logits[t].cpu(), ologits[t].detach()))
+        assert _rel(logits[t].cpu(), ologits[t].detach()) < LOGIT_TOL, (t, _rel(logits[t].cpu(), ologits[t].detach()))
         flat = logits[t].cpu().reshape(logits[t].shape[0], -1)
         stride = max(1, flat.shape[1] // 4096)
-        assert _rel(flat[:, ::stride], torch.from_numpy(gold[f"{phase}/logits/{t}"])) < 3e-2   # the reference's own logits
+        assert _rel(flat[:, ::stride], torch.from_numpy(gold[f"{phase}/logits/{t}"])) < LOGIT_TOL   # the reference's own logits
     ograds = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
     gmax = max(g.abs().max().item() for g in ograds.values())
     worst = (0.0, None)
@@ -83,9 +83,9 @@ def test_supervised_engine_matches_oracle_and_reference(golden_dir, name, phase,
             continue
         want = ograds[k]
         err, ref = (got - want).double().norm().item(), want.double().norm().item()
-        assert err <= 8e-2 * ref + 1e-5 * gmax * want.numel() ** 0.5, f"{k}: grad rel err {err / max(ref, 1e-12):.3e}"
+        assert err <= GRAD_TOL * ref + 1e-5 * gmax * want.numel() ** 0.5, f"{k}: grad rel err {err / max(ref, 1e-12):.3e}"
         worst = max(worst, (err / max(ref, 1e-12), k))
-        assert abs(got.double().norm().item() - float(gold[f"{phase}/gradnorm/{k}"])) <= 8e-2 * ref + 1e-5 * gmax * want.numel() ** 0.5
+        assert abs(got.double().norm().item() - float(gold[f"{phase}/gradnorm/{k}"])) <= GRAD_TOL * ref + 1e-5 * gmax * want.numel() ** 0.5
     observed(f"sup/{name}/{phase}", f"grad_worst/{worst[1]}", worst[0])
     print(f"[{name}/{phase}] loss hip={loss.item():.6f} oracle={oloss.item():.6f} worst grad rel err {worst}")
 
@@ -98,7 +98,7 @@ def test_model_forward_contract_probe(golden_dir):
     assert rec is None and msk is None and set(logits) == set(ds.dataset.targets)
     _, _, _, ologits = oracle({k: v.clone() for k, v in batch.items()}, "probe")
     for t in logits:
-        assert logits[t].shape == ologits[t].shape and _rel(logits[t].cpu(), ologits[t].detach()) < 3e-2
+        assert logits[t].shape == ologits[t].shape and _rel(logits[t].cpu(), ologits[t].detach()) < LOGIT_TOL
 
 
 @pytest.mark.parametrize("phase", ["probe", "finetune"])
