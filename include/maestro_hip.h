@@ -329,6 +329,13 @@ int mh_unpack_rows_add(const float* src, float* dst, int E, int K, int Kpad, voi
  * n % 4 == 0, step >= 1. */
 int mh_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float b1, float b2,
              float eps, float wd, int step, float grad_scale, void* stream);
+/* The same update that also refreshes the OCP e4m3 weight shadows of the fp8 path: p_fp8 = flat uint8 buffer with the
+ * parameters' offsets (same n), slot_map[i / 64] = scale slot of element i's weight or -1 (short; parameters are 64-element
+ * aligned), cast with scale[slot] (derived from the previous step's absmax by mh_fp8_update_scales), |new value| folded into
+ * amax[slot].  The slices passed must start at a multiple of 64 elements of the flat buffer the map was built for. */
+int mh_adamw_fp8(float* p, const float* g, float* m, float* v, void* p_bf16, void* p_fp8, const short* slot_map,
+                 const float* scale, float* amax, long n, float lr, float b1, float b2, float eps, float wd, int step,
+                 float grad_scale, void* stream);
 /* The same update with the per-step scalars read from DEVICE memory, so that the launch can sit inside a captured hipGraph
  * (the optimizer step overlapped with the next forward): hyper = f32 [5] = {lr, 1 - b1^step, sqrt(1 - b2^step), grad_scale,
  * active}; active == 0 makes the launch a no-op (no update pending). */

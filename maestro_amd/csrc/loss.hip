@@ -1,6 +1,5 @@
 // Masked reconstruction loss at patch layout + its gradient, bias-gradient column sums, casts, fused AdamW.
-#include "common.hpp"
-#include "../../include/maestro_hip.h"
+#include "gemm_common.hpp"
 
 namespace {
 
@@ -118,9 +117,15 @@ __global__ __launch_bounds__(256) void unpack_rows_add_kernel(const float* __res
 }
 
 // torch.optim.AdamW step (decoupled weight decay, bias correction), 4 elements per thread, grid-stride free.
+// fp8 shadows (C5 path): p8 = a flat uint8 buffer with the parameters' offsets; slot_map[i / 64] = scale slot of the weight
+// element i belongs to (-1: not an fp8 GEMM operand).  The cast uses the scale derived from the PREVIOUS step's absmax and
+// records this step's (delayed scaling: a weight moves by one learning-rate step at a time).
+struct Fp8Shadow { uint8_t* p8; const short* slot_map; const float* scale; float* amax; };
+
 __device__ __forceinline__ void adamw_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                              float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr, float b1, float b2,
-                                             float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                                             float eps, float wd, float bc1, float bc2_sqrt, float gscale,
+                                             Fp8Shadow f8 = Fp8Shadow{nullptr, nullptr, nullptr, nullptr}) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i) * gscale;
@@ -142,11 +147,31 @@ __device__ __forceinline__ void adamw_update(float* __restrict__ p, const float*
         u32x2 pk = {pack_bf2(pv[0], pv[1]), pack_bf2(pv[2], pv[3])};
         *reinterpret_cast<u32x2*>(pb + i) = pk;
     }
+    if (f8.p8) {
+        const int slot = f8.slot_map[i >> 6];
+        if (slot >= 0) {
+            const float s8 = f8.scale[slot];
+            f32x4 q8;
+            float mx = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { mx = fmaxf(mx, fabsf(pv[e])); q8[e] = fminf(fmaxf(pv[e] * s8, -448.f), 448.f); }
+            int a = __builtin_amdgcn_cvt_pk_fp8_f32(q8[0], q8[1], 0, false);
+            a = __builtin_amdgcn_cvt_pk_fp8_f32(q8[2], q8[3], a, true);
+            *reinterpret_cast<uint32_t*>(f8.p8 + i) = (uint32_t)a;
+            if (mx > 0.f) atomic_max_pos(f8.amax + slot, mx);   // looks before it adds: almost never an atomic after the first waves
+        }
+    }
 }
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr, float b1,
                                                     float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
     adamw_update(p, g, m, v, pb, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+}
+__global__ __launch_bounds__(256) void adamw_fp8_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr, float b1,
+                                                        float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
+                                                        Fp8Shadow f8) {
+    adamw_update(p, g, m, v, pb, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale, f8);
 }
 // per-step scalars from device memory: the launch is captured once and replayed with new values (see mh_adamw_dev)
 __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -238,6 +263,19 @@ extern "C" int mh_adamw(float* p, const float* g, float* m, float* v, void* p_bf
     const float bc2_sqrt = sqrtf(1.f - powf(b2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n, lr,
                        b1, b2, eps, wd, bc1, bc2_sqrt, grad_scale);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_adamw_fp8(float* p, const float* g, float* m, float* v, void* p_bf16, void* p_fp8, const short* slot_map,
+                            const float* scale, float* amax, long n, float lr, float b1, float b2, float eps, float wd, int step,
+                            float grad_scale, void* stream) {
+    MH_CHECK_ARG(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "mh_adamw_fp8: bad arguments (n %% 4 == 0, step >= 1)");
+    MH_CHECK_ARG(p_fp8 && slot_map && scale && amax && ((uintptr_t)p_fp8 % 4) == 0, "mh_adamw_fp8: fp8 shadow, slot map, scale and amax tables are required");
+    const float bc1 = 1.f - powf(b1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(b2, (float)step));
+    hipLaunchKernelGGL(adamw_fp8_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n, lr,
+                       b1, b2, eps, wd, bc1, bc2_sqrt, grad_scale, Fp8Shadow{(uint8_t*)p_fp8, slot_map, scale, amax});
     MH_LAUNCH_CHECK();
     return 0;
 }

@@ -176,7 +176,7 @@ class Stack:
                 for key, lin in (("qkv", attn.to_qkv), ("proj", attn.to_out[0]), ("fc1", ff.net[1]), ("fc2", ff.net[4])):
                     cache = eng._fp8_weights.get(id(lin.weight))
                     if cache is None:        # a holder shared by several groups registers its weights once
-                        cache = eng._fp8_weights[id(lin.weight)] = plan.add_weight(lin.weight.data)
+                        cache = eng._fp8_weights[id(lin.weight)] = plan.add_weight(lin.weight.data, eng.store.offset[id(lin.weight)])
                     d["w_" + key], d["sw_" + key] = cache
                 self.f8.append(d)
 
@@ -664,7 +664,7 @@ class MAEEngine(EngineBase):
             setattr(m, bname, getattr(m, bname).to(device))
         if dtype == "fp8":
             from maestro_amd.fp8 import Fp8Plan
-            self.fp8 = Fp8Plan(device)
+            self.fp8 = Fp8Plan(device, self.store.total)
         self._alloc()
         if self.fp8 is not None:
             self.fp8.finalize()
@@ -734,14 +734,14 @@ class MAEEngine(EngineBase):
         tot_w = sum(s.Dates * s.L for s in self.mods.values())
         self.loss_w = {n: (s.Dates * s.L) / tot_w for n, s in self.mods.items()}  # weight = D*H*W (model.py:239)
 
-    def _pack_conv_weights(self) -> None:
+    def _pack_conv_weights(self, fp8_done: bool = False) -> None:
         """Derived weight copies beyond the flat bf16 shadow (called wherever the shadows are refreshed: engine start,
         parameters changed behind the engine's back, after every fused AdamW step): the K-padded patch-embed weights and,
         in fp8 mode, the e4m3 weight shadows with their scales."""
         for name, s in self.mods.items():
             b = self.mb[name]
             hip.pack_rows_bf16(b["pe"].conv.weight, b["w_conv16"], self.E, s.K, s.Kpad)
-        if self.fp8 is not None:
+        if self.fp8 is not None and not fp8_done:     # (fp8_done: the fused AdamW has just written the shadows itself)
             self.fp8.refresh_weights()
 
     # ------------------------------------------------------------------------------------------ RNG (host)

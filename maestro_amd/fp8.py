@@ -24,8 +24,13 @@ U8 = torch.uint8
 
 
 class Fp8Plan:
-    def __init__(self, device) -> None:
+    def __init__(self, device, total: int = 0) -> None:
+        """``total``: element count of the engine's flat parameter buffer -- the e4m3 weight shadows live in ONE flat uint8
+        buffer with the same offsets, so that the fused AdamW (``mh_adamw_fp8``) can refresh them in its own pass."""
         self.device = device
+        self.w8_flat = torch.zeros(max(total, 4), dtype=U8, device=device)
+        self._slot_map = torch.full(((max(total, 64) + 63) // 64,), -1, dtype=torch.int16)
+        self.slot_map = None
         self._w_jobs, self._n_act = [], 0
         self.wsc = self.asc = None
         self._wbatch = None
@@ -37,10 +42,15 @@ class Fp8Plan:
     def eligible(K: int) -> bool:  # noqa: N803
         return K % 128 == 0 and K >= 128
 
-    def add_weight(self, master: torch.Tensor):
-        """``master``: the fp32 parameter view [N, K] inside the flat buffer -> (e4m3 shadow uint8 [N, K], scale slot)."""
-        w8 = torch.zeros(master.shape, dtype=U8, device=self.device)
+    def add_weight(self, master: torch.Tensor, offset: int):
+        """``master``: the fp32 parameter view [N, K] at ``offset`` of the flat buffer -> (e4m3 shadow uint8 [N, K], a view of
+        ``w8_flat`` at the same offset; scale slot)."""
+        n = master.numel()
+        w8 = self.w8_flat[offset: offset + n].view(master.shape)
         slot = len(self._w_jobs)
+        if slot > 32767 or offset % 64:
+            raise hip.HipExtensionError("Fp8Plan: too many weights for the int16 slot map / parameter not 64-element aligned")
+        self._slot_map[offset // 64: (offset + n + 63) // 64] = slot
         self._w_jobs.append(dict(src=master, dst=w8, slot=slot, format=hip.FP8_E4M3))
         return w8, slot
 
@@ -51,6 +61,7 @@ class Fp8Plan:
     def finalize(self) -> None:
         self.wsc = hip.Fp8Scales(max(1, len(self._w_jobs)), self.device)
         self.asc = hip.Fp8Scales(max(1, self._n_act), self.device)
+        self.slot_map = self._slot_map.to(self.device)
         if self._w_jobs:
             self._wbatch = hip.QuantBatch(self._w_jobs, self.wsc, self.device)
 
@@ -71,6 +82,15 @@ class Fp8Plan:
         else:
             self.wsc.update(fmt=hip.FP8_E4M3, margin=1)
             self._wbatch.launch(2)
+
+    def before_fused_adamw(self) -> bool:
+        """The fused AdamW (``mh_adamw_fp8``) refreshes the shadows in its own pass (5 -> 0 extra bytes per weight): derive this
+        step's scales from the previous absmax first.  False while the scales are not initialised (the caller then falls back
+        to ``refresh_weights`` after a plain update)."""
+        if self._wbatch is None or not self._w_ready:
+            return False
+        self.wsc.update(fmt=hip.FP8_E4M3, margin=1)
+        return True
 
     def quantize(self, src: torch.Tensor, dst: torch.Tensor, slot: int) -> None:
         """Activation cast with the current scale of ``slot`` + absmax for the next step (delayed scaling)."""

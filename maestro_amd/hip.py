@@ -400,6 +400,12 @@ def adamw(p, g, m, v, p_bf16, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
     call("mh_adamw", p, g, m, v, p_bf16, _L(n), _F(lr), _F(b1), _F(b2), _F(eps), _F(wd), _I(step), _F(grad_scale))
 
 
+def adamw_fp8(p, g, m, v, p_bf16, p_fp8, slot_map, scale, amax, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
+    """AdamW that also writes the e4m3 weight shadows (delayed scaling; see ``mh_adamw_fp8``)."""
+    call("mh_adamw_fp8", p, g, m, v, p_bf16, p_fp8, slot_map, scale, amax, _L(n), _F(lr), _F(b1), _F(b2), _F(eps), _F(wd), _I(step),
+         _F(grad_scale))
+
+
 _libm = None
 
 

@@ -64,15 +64,25 @@ class FusedAdamW:
         self.t += 1
         lr = self.lr if lr is None else lr
         lo, hi = self.lo, self.hi
-        split = min(max(split, lo), hi) // 4 * 4
+        plan = getattr(self.engine, "fp8", None)
+        fused8 = plan is not None and plan.before_fused_adamw()     # e4m3 weight shadows refreshed by the update itself
+        split = min(max(split, lo), hi) // 64 * 64
         for a, b in ((split, hi), (lo, split)):
             if a == lo and between is not None:
                 between()
-            if b > a:
+            if b > a and fused8 and a % 64 == 0:
+                hip.adamw_fp8(st.flat[a:b], st.grad[a:b], self.m[a - lo: b - lo], self.v[a - lo: b - lo], st.half[a:b],
+                              plan.w8_flat[a:b], plan.slot_map[a // 64:], plan.wsc.scale, plan.wsc.amax, b - a, lr, self.betas[0],
+                              self.betas[1], self.eps, self.wd, self.t, grad_scale)
+            elif b > a:
+                fused8 = False
                 hip.adamw(st.flat[a:b], st.grad[a:b], self.m[a - lo: b - lo], self.v[a - lo: b - lo], st.half[a:b], b - a, lr,
                           self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
         st.mark_synced()               # bf16 shadows were refreshed by the kernel itself
-        self.engine._pack_conv_weights()  # patch-embed weights live in a K-padded bf16 layout (+ the e4m3 shadows in fp8 mode)
+        if plan is not None:
+            self.engine._pack_conv_weights(fp8_done=fused8)  # K-padded patch-embed weights (+ e4m3 shadows unless fused above)
+        else:
+            self.engine._pack_conv_weights()                 # patch-embed weights live in a K-padded bf16 layout
         if roctx:
             torch.cuda.nvtx.range_pop()
 

@@ -211,3 +211,33 @@ def test_layernorm_fp8_output(dev):
     diff = (y8.cpu().int() - want).abs()
     assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 2e-3
     assert abs(float(amax) - float(ref.abs().max())) < 1e-4 * float(ref.abs().max())
+
+
+def test_adamw_fp8_refreshes_the_shadows_in_its_own_pass(dev):
+    """``mh_adamw_fp8`` = ``mh_adamw`` (bit-identical parameters, moments and bf16 shadow) + the e4m3 shadow of the elements the
+    slot map marks, cast with the slot's scale, absmax folded into the slot -- and nothing written where the map says -1."""
+    from maestro_amd import hip
+    g = torch.Generator().manual_seed(9)
+    n = 64 * 40
+    p0, grad = torch.randn(n, generator=g) * 0.05, torch.randn(n, generator=g) * 1e-3
+    slot_map = torch.full((n // 64,), -1, dtype=torch.int16)
+    slot_map[4:20], slot_map[24:40] = 0, 1                    # two "weights", gaps in front, between (biases / norms)
+    outs = []
+    for fused in (False, True):
+        p, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        half = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        p8 = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+        scale, amax = torch.tensor([64.0, 128.0], device=dev), torch.zeros(2, device=dev)
+        if fused:
+            hip.adamw_fp8(p, grad.to(dev), m, v, half, p8, slot_map.to(dev), scale, amax, n, 1e-3, 0.9, 0.99, 1e-8, 0.01, 1)
+        else:
+            hip.adamw(p, grad.to(dev), m, v, half, n, 1e-3, 0.9, 0.99, 1e-8, 0.01, 1)
+        torch.cuda.synchronize()
+        outs.append((p.cpu(), m.cpu(), v.cpu(), half.cpu(), p8.cpu(), amax.cpu()))
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b)
+    p_new, p8, amax = outs[1][0], outs[1][4], outs[1][5]
+    for slot, (lo, hi), sc in ((0, (4 * 64, 20 * 64), 64.0), (1, (24 * 64, 40 * 64), 128.0)):
+        want = _q((p_new[lo:hi] * sc).clamp(-448, 448), 0).view(torch.uint8)
+        assert torch.equal(p8[lo:hi], want) and float(amax[slot]) == float(p_new[lo:hi].abs().max())
+    assert bool((p8[: 4 * 64] == 7).all()) and bool((p8[20 * 64: 24 * 64] == 7).all())
