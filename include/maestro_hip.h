@@ -110,7 +110,7 @@ int mh_gemm_grouped(int layout, const MhGemmProblem* problems_device, int n_prob
  * transposed fp8 shadow), A8 = activations in e4m3 or gradients in e5m2 (a_format).  K %% 128 == 0, lda / ldb %% 16 == 0 (bytes).
  * descale_a / descale_b: DEVICE scalars 1 / scale of the per-tensor quantisers below (mh_quant_batched).  Optional c8
  * (bf16-output epilogues only): an e4m3 copy of the output times *c8_scale (the next fp8 GEMM's A operand: fc1 -> fc2),
- * with max |output| folded into *c8_amax (delayed scaling).  Replaces the nn.Linear calls inside vit_pytorch's Attention /
+ * with max |output| folded into the amax row c8_amax (delayed scaling; see MH_FP8_AMAX_PITCH).  Replaces the nn.Linear calls inside vit_pytorch's Attention /
  * FeedForward (call sites maestro/ssl/mae.py:135-174) when the step runs with fp8 operands. */
 enum { MH_FP8_E4M3 = 0, MH_FP8_E5M2 = 1 };
 int mh_gemm_fp8(int M, int N, int K, const void* A8, int lda, int a_format, const void* B8, int ldb, void* C, int ldc,
@@ -119,11 +119,19 @@ int mh_gemm_fp8(int M, int N, int K, const void* A8, int lda, int a_format, cons
                 float* c8_amax, void* stream);
 /* Per-tensor fp8 quantisation, batched over a job table (DEVICE array): job = one tensor of n elements (n %% 4 == 0), f32 or
  * bf16 source, `slot` = its entry in the scale / amax tables.  items: DEVICE array of work items job << 32 | chunk (chunks of
- * 4096 elements).  mode 0: amax[slot] = max(amax[slot], max |src|) only;  1: dst = fp8(src * scale[slot]) (+ the transposed
+ * 4096 elements).  mode 0: amax row of slot = max(itself, max |src|) only;  1: dst = fp8(src * scale[slot]) (+ the transposed
  * copy dst_t [cols, rows] of a [rows, cols] tensor when dst_t != NULL, cols %% 4 == 0);  2: cast AND fold max |src| into amax
  * (delayed scaling of activations: this step casts with the previous step's scale).  Values saturate at the format's largest
  * finite number.  mh_fp8_update_scales: scale = 2^(floor(log2(format_max / amax)) - margin_log2) (1 while amax is 0),
- * descale = 1 / scale, amax reset to 0 -- all on the device, capturable. */
+ * descale = 1 / scale, amax reset to 0 -- all on the device, capturable.
+ * amax tables: ONE ROW of MH_FP8_AMAX_PITCH floats per slot, not one float -- same-cache-line atomics retire at about one per
+ * 10 ns on MI355X (scripts/micro_amax.hip: 18432 LayerNorm rows folding into one word took 217 us instead of 19), so every
+ * workgroup folds into sub-slot (its index %% MH_FP8_AMAX_SUBSLOTS) of the row, MH_FP8_AMAX_STRIDE floats (256 bytes) apart; a
+ * slot's absmax is the maximum over its row, taken by mh_fp8_update_scales.  Every `amax` pointer of this header (c8_amax,
+ * y8_amax, the tables of mh_quant_batched / mh_adamw_fp8) points at such rows. */
+#define MH_FP8_AMAX_SUBSLOTS 32
+#define MH_FP8_AMAX_STRIDE 64
+#define MH_FP8_AMAX_PITCH (MH_FP8_AMAX_SUBSLOTS * MH_FP8_AMAX_STRIDE)
 typedef struct MhQuantJob {
     const void* src; void* dst; void* dst_t;
     long n;
@@ -143,7 +151,7 @@ int mh_fp8_update_scales(float* amax, float* scale, float* descale, int n, float
 int mh_layernorm_fwd(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y, int y_L,
                      int y_off, int y_is_f32, float* mean, float* rstd, int B, int n, int dim, float eps, void* stream);
 /* The same with a second output for the fp8 path: y8 = OCP e4m3 of (y * *y8_scale) in y's row map (the A operand of the next
- * mh_gemm_fp8), max |y| folded into *y8_amax (optional; delayed scaling).  y is bf16 (the backward's wgrad reads it). */
+ * mh_gemm_fp8), max |y| folded into the amax row y8_amax (optional; delayed scaling).  y is bf16 (the backward's wgrad reads it). */
 int mh_layernorm_fwd_fp8(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y, int y_L,
                          int y_off, float* mean, float* rstd, int B, int n, int dim, float eps, void* y8,
                          const float* y8_scale, float* y8_amax, void* stream);
@@ -332,7 +340,7 @@ int mh_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n,
 /* The same update that also refreshes the OCP e4m3 weight shadows of the fp8 path: p_fp8 = flat uint8 buffer with the
  * parameters' offsets (same n), slot_map[i / 64] = scale slot of element i's weight or -1 (short; parameters are 64-element
  * aligned), cast with scale[slot] (derived from the previous step's absmax by mh_fp8_update_scales), |new value| folded into
- * amax[slot].  The slices passed must start at a multiple of 64 elements of the flat buffer the map was built for. */
+ * amax row `slot`.  The slices passed must start at a multiple of 64 elements of the flat buffer the map was built for. */
 int mh_adamw_fp8(float* p, const float* g, float* m, float* v, void* p_bf16, void* p_fp8, const short* slot_map,
                  const float* scale, float* amax, long n, float lr, float b1, float b2, float eps, float wd, int step,
                  float grad_scale, void* stream);

@@ -32,10 +32,15 @@ __device__ __forceinline__ u32x2 pack_fp8x8(f32x4 lo, f32x4 hi, float s) {
     b = __builtin_amdgcn_cvt_pk_fp8_f32(hi[2], hi[3], b, true);
     return (u32x2){(uint32_t)a, (uint32_t)b};
 }
-__device__ __forceinline__ void atomic_max_pos(float* dst, float v) {   // v >= 0: the int order of the bits is the float order
-    // thousands of workgroups fold into ONE word per tensor: look first (a possibly stale value only costs a redundant
-    // atomic, never a lost maximum) so that after the first few arrivals almost nobody issues the same-address atomic
-    if (v > __builtin_nontemporal_load(dst)) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(v));
+// Fold an absmax (v >= 0: the int order of the bits is the float order) into a slot's amax ROW (MH_FP8_AMAX_PITCH floats).
+// Atomics on one cache line retire at ~10 ns apiece whatever the address inside it (scripts/micro_amax.hip; a look-before-
+// you-add needs an agent-scope load to see other CUs' maxima at all -- plain and nontemporal loads are served stale -- and
+// still leaves the ~8000 waves resident at launch to storm the word: +80 us on a 7 us LayerNorm).  32 sub-slots 256 bytes
+// apart spread the adds over L2 channels: +0.5 us, no look needed; mh_fp8_update_scales takes the maximum over the row.
+__device__ __forceinline__ void atomic_max_pos(float* row, float v) {
+    const unsigned k = ((blockIdx.x + blockIdx.y * gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (MH_FP8_AMAX_SUBSLOTS - 1);
+    __hip_atomic_fetch_max(reinterpret_cast<int*>(row) + k * MH_FP8_AMAX_STRIDE, __float_as_int(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // gemm_dma.hip: the LDS-DMA tile family (tile = MH_TILE_DMA_*); -2 = not eligible, nothing launched

@@ -122,12 +122,14 @@ __global__ __launch_bounds__(256) void unpack_rows_add_kernel(const float* __res
 // records this step's (delayed scaling: a weight moves by one learning-rate step at a time).
 struct Fp8Shadow { uint8_t* p8; const short* slot_map; const float* scale; float* amax; };
 
-__device__ __forceinline__ void adamw_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// returns the fp8 scale slot of this lane's four elements (-1: none) and their absmax in *amax_out
+__device__ __forceinline__ int adamw_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                              float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr, float b1, float b2,
                                              float eps, float wd, float bc1, float bc2_sqrt, float gscale,
-                                             Fp8Shadow f8 = Fp8Shadow{nullptr, nullptr, nullptr, nullptr}) {
+                                             Fp8Shadow f8 = Fp8Shadow{nullptr, nullptr, nullptr, nullptr},
+                                             float* amax_out = nullptr) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;
+    if (i >= n) return -1;
     const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i) * gscale;
     f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
     f32x4 mv = *reinterpret_cast<const f32x4*>(m + i);
@@ -158,9 +160,11 @@ __device__ __forceinline__ void adamw_update(float* __restrict__ p, const float*
             int a = __builtin_amdgcn_cvt_pk_fp8_f32(q8[0], q8[1], 0, false);
             a = __builtin_amdgcn_cvt_pk_fp8_f32(q8[2], q8[3], a, true);
             *reinterpret_cast<uint32_t*>(f8.p8 + i) = (uint32_t)a;
-            if (mx > 0.f) atomic_max_pos(f8.amax + slot, mx);   // looks before it adds: almost never an atomic after the first waves
+            *amax_out = mx;
+            return slot;
         }
     }
+    return -1;
 }
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr, float b1,
@@ -171,7 +175,31 @@ __global__ __launch_bounds__(256) void adamw_fp8_kernel(float* __restrict__ p, c
                                                         float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr, float b1,
                                                         float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
                                                         Fp8Shadow f8) {
-    adamw_update(p, g, m, v, pb, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale, f8);
+    // absmax: 80 M lanes adding to one word per tensor took 22 ms per step -- fold per wave and per workgroup first (a workgroup
+    // spans 1024 elements, i.e. one tensor except at the few tensor boundaries), then one add into a sub-slot of the amax row
+    __shared__ float red_mx[4];
+    __shared__ int red_slot[4];
+    float mx = 0.f;
+    const int slot = adamw_update(p, g, m, v, pb, n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale, f8, &mx);
+    const int w = threadIdx.x >> 6;
+    const int slot0 = __builtin_amdgcn_readfirstlane(slot);      // first ACTIVE lane: all lanes are active here
+    const bool uniform = __all(slot == slot0);
+    if (uniform) {
+        mx = wave_max(mx);
+    } else if (slot >= 0 && mx > 0.f) {
+        atomic_max_pos(f8.amax + (size_t)slot * MH_FP8_AMAX_PITCH, mx);   // a wave across a tensor boundary: rare
+    }
+    if ((threadIdx.x & 63) == 0) { red_mx[w] = uniform ? mx : 0.f; red_slot[w] = uniform ? slot0 : -1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (red_slot[0] == red_slot[1] && red_slot[0] == red_slot[2] && red_slot[0] == red_slot[3]) {
+            const float m4 = fmaxf(fmaxf(red_mx[0], red_mx[1]), fmaxf(red_mx[2], red_mx[3]));
+            if (red_slot[0] >= 0 && m4 > 0.f) atomic_max_pos(f8.amax + (size_t)red_slot[0] * MH_FP8_AMAX_PITCH, m4);
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (red_slot[k] >= 0 && red_mx[k] > 0.f) atomic_max_pos(f8.amax + (size_t)red_slot[k] * MH_FP8_AMAX_PITCH, red_mx[k]);
+        }
+    }
 }
 // per-step scalars from device memory: the launch is captured once and replayed with new values (see mh_adamw_dev)
 __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

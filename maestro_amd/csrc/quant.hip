@@ -1,6 +1,7 @@
 // fp8 quantisers of the C5 path (operands of mh_gemm_fp8): per-TENSOR power-of-two scales kept in device memory, so that
 // the whole scaling loop -- absmax, scale update, cast -- is capturable in the step's hipGraphs and never read by the host.
-//   scale table: one float slot per tensor: scale (multiplier before the cast), descale = 1 / scale (GEMM epilogue), amax.
+//   scale table: one float slot per tensor: scale (multiplier before the cast), descale = 1 / scale (GEMM epilogue); amax: one
+//                ROW of MH_FP8_AMAX_PITCH floats per slot (sub-slots against same-line atomics, see atomic_max_pos).
 //   weights:     every optimizer step  absmax (batched) -> update -> cast (batched; optionally also the TRANSPOSED copy the
 //                dgrad reads, so that both GEMM directions stay K-minor x K-minor)
 //   activations: delayed scaling -- the cast of step t uses the scale derived from step t-1's amax and folds |x| of step t
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void quant_batched_kernel(const MhQuantJob* __
         __syncthreads();
         if (threadIdx.x == 0) {
             mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-            if (mx > 0.f) atomic_max_pos(amax + jb.slot, mx);
+            if (mx > 0.f) atomic_max_pos(amax + (size_t)jb.slot * MH_FP8_AMAX_PITCH, mx);
         }
     }
 }
@@ -75,9 +76,12 @@ __global__ __launch_bounds__(256) void quant_batched_kernel(const MhQuantJob* __
 // scale = 2^(floor(log2(fmax / amax)) - margin) (1 while amax is 0 or not finite), descale = 1 / scale, amax reset to 0
 __global__ __launch_bounds__(256) void update_scales_kernel(float* __restrict__ amax, float* __restrict__ scale,
                                                             float* __restrict__ descale, int n, float fmax8, int margin) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;   // one wave per slot: maximum over its amax row
     if (i >= n) return;
-    const float a = amax[i];
+    float* row = amax + (size_t)i * MH_FP8_AMAX_PITCH + (l & (MH_FP8_AMAX_SUBSLOTS - 1)) * MH_FP8_AMAX_STRIDE;
+    const float a = wave_max(*row);
+    if (l < MH_FP8_AMAX_SUBSLOTS) *row = 0.f;
+    if (l != 0) return;
     float s = 1.f;
     if (a > 0.f && a < 3.0e38f) {
         int e = (int)floorf(log2f(fmax8 / a)) - margin;
@@ -86,7 +90,6 @@ __global__ __launch_bounds__(256) void update_scales_kernel(float* __restrict__ 
     }
     scale[i] = s;
     descale[i] = 1.f / s;
-    amax[i] = 0.f;
 }
 
 }  // namespace
@@ -105,7 +108,7 @@ extern "C" int mh_quant_batched(const MhQuantJob* jobs_device, const unsigned lo
 extern "C" int mh_fp8_update_scales(float* amax, float* scale, float* descale, int n, float format_max, int margin_log2,
                                     void* stream) {
     MH_CHECK_ARG(amax && scale && descale && n > 0 && format_max > 0.f, "mh_fp8_update_scales: bad arguments");
-    hipLaunchKernelGGL(update_scales_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, amax, scale, descale, n,
+    hipLaunchKernelGGL(update_scales_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream, amax, scale, descale, n,
                        format_max, margin_log2);
     MH_LAUNCH_CHECK();
     return 0;

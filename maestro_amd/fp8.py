@@ -112,7 +112,7 @@ class Fp8Plan:
         return self.asc.descale[slot: slot + 1]
 
     def a_amax(self, slot):
-        return self.asc.amax[slot: slot + 1]
+        return self.asc.amax[slot]          # the slot's amax ROW
 
     def w_descale(self, slot):
         return self.wsc.descale[slot: slot + 1]

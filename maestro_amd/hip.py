@@ -770,14 +770,22 @@ class _MhQuantJob(ctypes.Structure):
                 ("format", ctypes.c_int), ("reserved", ctypes.c_int)]
 
 
+AMAX_PITCH = 32 * 64   # MH_FP8_AMAX_SUBSLOTS * MH_FP8_AMAX_STRIDE
+
+
 class Fp8Scales:
-    """Scale / descale / amax tables (one slot per quantised tensor), all on the device."""
+    """Scale / descale / amax tables (one slot per quantised tensor), all on the device.  ``amax`` is [n_slots, AMAX_PITCH]: the
+    kernels fold into one of 32 sub-slots of a slot's row (``MH_FP8_AMAX_PITCH`` in the header: same-line atomics are slow);
+    ``absmax(slot)`` is the maximum over the row."""
 
     def __init__(self, n_slots: int, device) -> None:
         self.n = n_slots
         self.scale = torch.ones(n_slots, dtype=torch.float32, device=device)
         self.descale = torch.ones(n_slots, dtype=torch.float32, device=device)
-        self.amax = torch.zeros(n_slots, dtype=torch.float32, device=device)
+        self.amax = torch.zeros(n_slots, AMAX_PITCH, dtype=torch.float32, device=device)
+
+    def absmax(self, slot: int) -> float:
+        return float(self.amax[slot].max())
 
     def update(self, lo: int = 0, hi: int | None = None, fmt: int = FP8_E4M3, margin: int = 1) -> None:
         """``scale = 2^(floor(log2(max / amax)) - margin)`` for slots ``lo .. hi-1``; resets their amax."""
