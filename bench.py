@@ -246,6 +246,9 @@ def main() -> None:
                     help="A/B aid: AdamW of step t inside the forward of step t+1 instead of at the end of the step (pretrain)")
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="N=1 under torch.distributed.run: create the one-rank RCCL group and run the bucketed exchange plan")
+    ap.add_argument("--rehearse-dry", action="store_true",
+                    help="the same launch plan (gradient hooks, backward segments, two-part AdamW) without a process group: what the "
+                         "plan itself costs, without RCCL's one-rank self-copies")
     ap.add_argument("--shapes", action="store_true", help="print per-shape kernel times to stderr (diagnostic)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -283,7 +286,7 @@ def main() -> None:
     torch.manual_seed(42 + rank)     # per-rank mask draws from here on
     if args.phase == "pretrain":
         loop = PretrainLoop(model, args.batch, dev, loss=args.loss, total_steps=args.steps + args.warmup, world_size=world,
-                            exchange=True if args.rehearse_exchange else None,
+                            exchange=True if (args.rehearse_exchange or args.rehearse_dry) else None,
                             overlap_optimizer=args.overlap_optimizer, dtype=args.dtype)
     else:
         loop = SupervisedLoop(model, args.batch, dev, phase=args.phase, total_steps=args.steps + args.warmup, world_size=world)

@@ -46,6 +46,7 @@ int mh_version(void);
 #define MH_GEMM_AUX_DGELU 128 /* with MH_GEMM_GELU: aux_out receives GELU'(pre-activation) (bf16) instead of the pre-activation: the
                                * CDF / PDF are already at hand in the forward epilogue, so the backward only multiplies */
 #define MH_GEMM_MULAUX 256    /* bf16 output only: C *= aux_in[M, N] (bf16) -- the backward of GELU with the saved derivative */
+#define MH_GEMM_C8_E5M2 512   /* mh_gemm_fp8 only: the fp8 copy c8 of the output is e5m2 (a gradient: the next dgrad's A operand) */
 int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                  int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                  int ldaux, float* colsum, void* stream);
@@ -140,6 +141,11 @@ typedef struct MhQuantJob {
 int mh_quant_batched(const MhQuantJob* jobs_device, const unsigned long* items_device, int n_items, const float* scale,
                      float* amax, int mode, void* stream);
 int mh_fp8_update_scales(float* amax, float* scale, float* descale, int n, float format_max, int margin_log2, void* stream);
+/* Byte transposes, batched: dst [cols, rows] = src [rows, cols]^T for every job (rows, cols %% 64 == 0, 16-byte aligned) -- the
+ * fp8 dgrad C = dY W needs W^T K-minor ([in, out] for an nn.Linear weight [out, in]): the e4m3 weight shadows are transposed
+ * once per optimizer step.  items: DEVICE array of job << 32 | tile (64 x 64-byte tiles, row-major over the source). */
+typedef struct MhTransposeJob { const void* src; void* dst; int rows, cols; } MhTransposeJob;
+int mh_transpose_u8_batched(const MhTransposeJob* jobs_device, const unsigned long* items_device, int n_items, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- LayerNorm
  * y = (x - mean) * rstd * gamma + beta over the last dim; x f32 (residual stream), y bf16 (GEMM operand) or f32.

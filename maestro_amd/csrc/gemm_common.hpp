@@ -19,17 +19,27 @@ struct GemmParams {
     uint8_t* c8 = nullptr; const float* c8_scale = nullptr; float* c8_amax = nullptr; int ldc8 = 0;
 };
 
-// 8 floats -> 8 OCP e4m3 bytes (saturating at +-448: e4m3fn has no infinity, an overflow would become NaN)
-__device__ __forceinline__ u32x2 pack_fp8x8(f32x4 lo, f32x4 hi, float s) {
+// 8 floats -> 8 OCP fp8 bytes, e4m3 (saturating at +-448: e4m3fn has no infinity, an overflow would become NaN) or e5m2
+// (gradients; saturating at +-57344)
+__device__ __forceinline__ u32x2 pack_fp8x8(f32x4 lo, f32x4 hi, float s, bool e5m2 = false) {
+    const float lim = e5m2 ? 57344.f : 448.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        lo[e] = fminf(fmaxf(lo[e] * s, -448.f), 448.f);
-        hi[e] = fminf(fmaxf(hi[e] * s, -448.f), 448.f);
+        lo[e] = fminf(fmaxf(lo[e] * s, -lim), lim);
+        hi[e] = fminf(fmaxf(hi[e] * s, -lim), lim);
     }
-    int a = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], 0, false);
-    a = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], a, true);
-    int b = __builtin_amdgcn_cvt_pk_fp8_f32(hi[0], hi[1], 0, false);
-    b = __builtin_amdgcn_cvt_pk_fp8_f32(hi[2], hi[3], b, true);
+    int a, b;
+    if (e5m2) {
+        a = __builtin_amdgcn_cvt_pk_bf8_f32(lo[0], lo[1], 0, false);
+        a = __builtin_amdgcn_cvt_pk_bf8_f32(lo[2], lo[3], a, true);
+        b = __builtin_amdgcn_cvt_pk_bf8_f32(hi[0], hi[1], 0, false);
+        b = __builtin_amdgcn_cvt_pk_bf8_f32(hi[2], hi[3], b, true);
+    } else {
+        a = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], 0, false);
+        a = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], a, true);
+        b = __builtin_amdgcn_cvt_pk_fp8_f32(hi[0], hi[1], 0, false);
+        b = __builtin_amdgcn_cvt_pk_fp8_f32(hi[2], hi[3], b, true);
+    }
     return (u32x2){(uint32_t)a, (uint32_t)b};
 }
 // Fold an absmax (v >= 0: the int order of the bits is the float order) into a slot's amax ROW (MH_FP8_AMAX_PITCH floats).
@@ -152,7 +162,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                     u32x4 pk = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
                     *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
                     if (p.c8) {
-                        *reinterpret_cast<u32x2*>(p.c8 + (size_t)m * p.ldc8 + n) = pack_fp8x8(lo, hi, s8);
+                        *reinterpret_cast<u32x2*>(p.c8 + (size_t)m * p.ldc8 + n) = pack_fp8x8(lo, hi, s8, p.flags & MH_GEMM_C8_E5M2);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) amax8 = fmaxf(amax8, fmaxf(fabsf(lo[e]), fabsf(hi[e])));
                     }

@@ -92,7 +92,36 @@ __global__ __launch_bounds__(256) void update_scales_kernel(float* __restrict__ 
     descale[i] = 1.f / s;
 }
 
+// dst [cols, rows] = src [rows, cols]^T, bytes; one 64 x 64 tile per workgroup through LDS (16-byte global accesses both ways)
+__global__ __launch_bounds__(256) void transpose_u8_kernel(const MhTransposeJob* __restrict__ jobs, const uint64_t* __restrict__ items) {
+    __shared__ __attribute__((aligned(16))) uint8_t t[64][80];
+    const uint64_t it = items[blockIdx.x];
+    const MhTransposeJob jb = jobs[it >> 32];
+    const int tiles_c = jb.cols >> 6, tile = (int)(uint32_t)it;
+    const int tr = tile / tiles_c, tc = tile - tr * tiles_c;
+    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(jb.src);
+    uint8_t* dst = reinterpret_cast<uint8_t*>(jb.dst);
+    *reinterpret_cast<u32x4*>(&t[r][16 * q]) =
+        *reinterpret_cast<const u32x4*>(src + (size_t)(tr * 64 + r) * jb.cols + tc * 64 + 16 * q);
+    __syncthreads();
+    u32x4 w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        w[k] = (uint32_t)t[16 * q + 4 * k][r] | ((uint32_t)t[16 * q + 4 * k + 1][r] << 8) | ((uint32_t)t[16 * q + 4 * k + 2][r] << 16) |
+               ((uint32_t)t[16 * q + 4 * k + 3][r] << 24);
+    *reinterpret_cast<u32x4*>(dst + (size_t)(tc * 64 + r) * jb.rows + tr * 64 + 16 * q) = w;
+}
+
 }  // namespace
+
+extern "C" int mh_transpose_u8_batched(const MhTransposeJob* jobs_device, const unsigned long* items_device, int n_items, void* stream) {
+    MH_CHECK_ARG(jobs_device && items_device && n_items > 0, "mh_transpose_u8_batched: bad arguments");
+    hipLaunchKernelGGL(transpose_u8_kernel, dim3(n_items), dim3(256), 0, (hipStream_t)stream, jobs_device,
+                       reinterpret_cast<const uint64_t*>(items_device));
+    MH_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int mh_quant_batched(const MhQuantJob* jobs_device, const unsigned long* items_device_, int n_items, const float* scale,
                                 float* amax, int mode, void* stream) {

@@ -176,8 +176,16 @@ class Stack:
                 for key, lin in (("qkv", attn.to_qkv), ("proj", attn.to_out[0]), ("fc1", ff.net[1]), ("fc2", ff.net[4])):
                     cache = eng._fp8_weights.get(id(lin.weight))
                     if cache is None:        # a holder shared by several groups registers its weights once
-                        cache = eng._fp8_weights[id(lin.weight)] = plan.add_weight(lin.weight.data, eng.store.offset[id(lin.weight)])
-                    d["w_" + key], d["sw_" + key] = cache
+                        off = eng.store.offset[id(lin.weight)]
+                        w8, slot = plan.add_weight(lin.weight.data, off)
+                        cache = eng._fp8_weights[id(lin.weight)] = (w8, slot, plan.add_transposed(w8, off))
+                    d["w_" + key], d["sw_" + key], d["wt_" + key] = cache
+                # fp8 dgrad: e5m2 copies of the four gradient operands (d layer output, d attention residual, d fc1-out, d qkv)
+                d["dgrad"] = plan.dgrad and all(d["wt_" + k] is not None for k in ("qkv", "proj", "fc1", "fc2"))
+                if d["dgrad"]:
+                    d.update(gy8=e(M, dim, dt=U8), mid8=e(M, dim, dt=U8), dh8=e(M, mlp, dt=U8), dqkv8=e(M, 3 * self.inner, dt=U8),
+                             g_gy=plan.add_gradient(), g_mid=plan.add_gradient(), g_dh=plan.add_gradient(),
+                             g_dqkv=plan.add_gradient())
                 self.f8.append(d)
 
     @property
@@ -304,14 +312,32 @@ class Stack:
             mid = self.dxa if cur is not self.dxa else self.dxb
             nxt = self.dxa if mid is not self.dxa else self.dxb
             nxt16 = self.saved[l - 1]["gy16"] if l > 0 else self.dx0_16
+            # fp8 dgrad (e5m2 gradients x transposed e4m3 weights); the first backward only records the gradients' absmax
+            f = self.f8[l] if self.f8 is not None and self.f8[l]["dgrad"] else None
+            plan = getattr(eng, "fp8", None)
+            f8 = f is not None and plan.grad_ready
+            if f is not None:
+                plan.quantize_grad(cur16, f["gy8"], f["g_gy"])
             # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-            hip.gemm(hip.GEMM_NN, M, mlp, dim, cur16, dim, ps.h(fc2.weight), mlp, dh, mlp, hip.MULAUX | hip.COLSUM,
-                     aux_in=s["hpre"], ldaux=mlp, colsum=s["cs"] if defer else self.cs_ws)
+            if f8:
+                hip.gemm_fp8(M, mlp, dim, f["gy8"], dim, f["wt_fc2"], dim, dh, mlp, plan.g_descale(f["g_gy"]),
+                             plan.w_descale(f["sw_fc2"]), flags=hip.MULAUX | hip.COLSUM | hip.C8_E5M2, a_format=hip.FP8_E5M2,
+                             aux_in=s["hpre"], ldaux=mlp, colsum=s["cs"] if defer else self.cs_ws, c8=f["dh8"], ldc8=mlp,
+                             c8_scale=plan.g_scale(f["g_dh"]), c8_amax=plan.g_amax(f["g_dh"]))
+            else:
+                hip.gemm(hip.GEMM_NN, M, mlp, dim, cur16, dim, ps.h(fc2.weight), mlp, dh, mlp, hip.MULAUX | hip.COLSUM,
+                         aux_in=s["hpre"], ldaux=mlp, colsum=s["cs"] if defer else self.cs_ws)
+                if f is not None:
+                    plan.quantize_grad(dh, f["dh8"], f["g_dh"])      # calibration: absmax only
             if not defer:
                 hip.colsum(self.cs_ws, ps.g(fc1.bias), self.cs_rows, mlp, mlp)   # fc1 bias gradient from the block partials
                 hip.gemm(hip.GEMM_TN, dim, mlp, M, cur16, dim, s["act"], mlp, ps.g(fc2.weight), mlp, AT)
                 hip.gemm(hip.GEMM_TN, mlp, dim, M, dh, mlp, s["h2"], dim, ps.g(fc1.weight), dim, AT)
-            hip.gemm(hip.GEMM_NN, M, dim, mlp, dh, mlp, ps.h(fc1.weight), dim, self.dh2, dim)
+            if f8:
+                hip.gemm_fp8(M, dim, mlp, f["dh8"], mlp, f["wt_fc1"], mlp, self.dh2, dim, plan.g_descale(f["g_dh"]),
+                             plan.w_descale(f["sw_fc1"]), a_format=hip.FP8_E5M2)
+            else:
+                hip.gemm(hip.GEMM_NN, M, dim, mlp, dh, mlp, ps.h(fc1.weight), dim, self.dh2, dim)
             if defer:   # parameter gradients: partial rows now, one batched reduce per segment (reduce_jobs)
                 hip.layernorm_bwd_partial(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16, s["ws2"],
                                           1, M, dim)
@@ -319,13 +345,25 @@ class Stack:
                 hip.layernorm_bwd(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16,
                                   ps.g(ln2.weight), ps.g(ln2.bias), ps.g(proj.bias), self.ln_ws, 1, M, dim)
             # ---- attention: x_mid = x_in + proj(attn(qkv(LN1(x_in))))
-            hip.gemm(hip.GEMM_NN, M, inner, dim, mid16, dim, ps.h(proj.weight), inner, self.do, inner)
+            if f is not None:
+                plan.quantize_grad(mid16, f["mid8"], f["g_mid"])
+            if f8:
+                hip.gemm_fp8(M, inner, dim, f["mid8"], dim, f["wt_proj"], dim, self.do, inner, plan.g_descale(f["g_mid"]),
+                             plan.w_descale(f["sw_proj"]), a_format=hip.FP8_E5M2)
+            else:
+                hip.gemm(hip.GEMM_NN, M, inner, dim, mid16, dim, ps.h(proj.weight), inner, self.do, inner)
             if not defer:
                 hip.gemm(hip.GEMM_TN, dim, inner, M, mid16, dim, s["o"], inner, ps.g(proj.weight), inner, AT)
             hip.attn_bwd(s["qkv"], s["o"], self.do, s["lse"], self.delta, dqkv, self.Bn, self.N, self.H, self.Dh, attn.scale)
             if not defer:
                 hip.gemm(hip.GEMM_TN, 3 * inner, dim, M, dqkv, 3 * inner, s["h1"], dim, ps.g(attn.to_qkv.weight), dim, AT)
-            hip.gemm(hip.GEMM_NN, M, dim, 3 * inner, dqkv, 3 * inner, ps.h(attn.to_qkv.weight), dim, self.dh2, dim)
+            if f is not None:
+                plan.quantize_grad(dqkv, f["dqkv8"], f["g_dqkv"])
+            if f8:
+                hip.gemm_fp8(M, dim, 3 * inner, f["dqkv8"], 3 * inner, f["wt_qkv"], 3 * inner, self.dh2, dim,
+                             plan.g_descale(f["g_dqkv"]), plan.w_descale(f["sw_qkv"]), a_format=hip.FP8_E5M2)
+            else:
+                hip.gemm(hip.GEMM_NN, M, dim, 3 * inner, dqkv, 3 * inner, ps.h(attn.to_qkv.weight), dim, self.dh2, dim)
             prev_fc2_bias = ps.g(self.t.layers[l - 1][1].net[4].bias) if l > 0 else None  # = colsum(dx_out of layer l-1)
             if defer:
                 hip.layernorm_bwd_partial(self.dh2, M, 0, x_in, M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid, nxt, nxt16,
@@ -741,8 +779,11 @@ class MAEEngine(EngineBase):
         for name, s in self.mods.items():
             b = self.mb[name]
             hip.pack_rows_bf16(b["pe"].conv.weight, b["w_conv16"], self.E, s.K, s.Kpad)
-        if self.fp8 is not None and not fp8_done:     # (fp8_done: the fused AdamW has just written the shadows itself)
-            self.fp8.refresh_weights()
+        if self.fp8 is not None:
+            if fp8_done:                                  # the fused AdamW has just written the shadows itself
+                self.fp8.refresh_transposed()
+            else:
+                self.fp8.refresh_weights()
 
     # ------------------------------------------------------------------------------------------ RNG (host)
     def draw_masks(self, generator=None):
@@ -1107,8 +1148,13 @@ class MAEEngine(EngineBase):
     def _enc_cuts(self) -> list:
         # encoder side: with a gradient hook (data parallel) cut it into layer ranges so the all-reduce of the finished
         # slices overlaps the remaining layers (~85 % of the parameters live in the group encoders)
+        # MAESTRO_ENC_CUTS (1..4, default 3): every cut costs a join of the group streams and a smaller grouped wgrad launch
+        # (measured at N = 1, C3: +2.3 % for three), every missing one leaves more gradient bytes to reduce after the backward
         depth = max(st.depth for st in self.enc.values())
-        return [depth, 0] if self.grad_hook is None or depth < 3 else [depth, depth - depth // 3, depth // 3, 0]
+        n = max(1, min(4, int(os.environ.get("MAESTRO_ENC_CUTS", "3"))))
+        if self.grad_hook is None or depth < 3 or n == 1:
+            return [depth, 0]
+        return [depth] + [depth - (i * depth) // n for i in range(1, n)] + [0]
 
     def backward(self, grad_scale: float = 1.0) -> None:
         """Backward of the last ``forward`` (d loss = 1) into the flat grad buffer, which must have been zeroed for this
@@ -1123,6 +1169,8 @@ class MAEEngine(EngineBase):
         key = getattr(self, "_cur_key", None)
         plan = self._plan = self._wgrad_plan()
         sfx = f":{plan}:{'h' if self.grad_hook is not None else 'n'}"   # graphs are specific to the launch plan
+        if self.fp8 is not None and self.fp8.dgrad:
+            sfx += ":f8" if self.fp8.grad_ready else ":cal"       # (the first backward calibrates the gradient scales in bf16)
         with self._tuning_pass("backward"):
             self._segment("bwd_dec" + sfx, key, self._bwd_decoder_side)
             if self.joint is not None:
@@ -1131,6 +1179,8 @@ class MAEEngine(EngineBase):
             for i in range(len(cuts) - 1):
                 self._segment(f"bwd_enc{i}" + sfx, key, lambda hi=cuts[i], lo=cuts[i + 1], first=(i == 0), last=(i == len(cuts) - 2):
                               self._bwd_encoder_side(hi, lo, first, last))
+        if self.fp8 is not None:
+            self.fp8.end_of_backward()      # next step's e5m2 gradient scales from this backward's absmax values
 
     def _bwd_decoder_side(self) -> None:
         m, E, Dd, ps = self.model, self.E, self.Dd, self.store  # noqa: N806

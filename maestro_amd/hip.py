@@ -17,7 +17,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libmaestro_hip.so"
 _lib = None
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-OUT_F32, BIAS, GELU, RESIDUAL, DGELU, ATOMIC, COLSUM, AUX_DGELU, MULAUX = 1, 2, 4, 8, 16, 32, 64, 128, 256
+OUT_F32, BIAS, GELU, RESIDUAL, DGELU, ATOMIC, COLSUM, AUX_DGELU, MULAUX, C8_E5M2 = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 
 class HipExtensionError(RuntimeError):
@@ -792,6 +792,32 @@ class Fp8Scales:
         hi = self.n if hi is None else hi
         call("mh_fp8_update_scales", self.amax[lo:hi], self.scale[lo:hi], self.descale[lo:hi], _I(hi - lo), _F(FP8_MAX[fmt]),
              _I(margin))
+
+
+class _MhTransposeJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int)]
+
+
+class TransposeBatch:
+    """``mh_transpose_u8_batched``: ``pairs`` = (src uint8 [rows, cols], dst uint8 [cols, rows]), rows and cols multiples of 64."""
+
+    def __init__(self, pairs, device) -> None:
+        arr = (_MhTransposeJob * len(pairs))()
+        items, self.keep = [], []
+        for i, (src, dst) in enumerate(pairs):
+            rows, cols = src.shape
+            if rows % 64 or cols % 64 or tuple(dst.shape) != (cols, rows) or not (src.is_contiguous() and dst.is_contiguous()) \
+                    or src.dtype != torch.uint8 or dst.dtype != torch.uint8 or (src.data_ptr() | dst.data_ptr()) % 16:
+                raise HipExtensionError("TransposeBatch: contiguous 16-byte aligned uint8 [rows, cols] -> [cols, rows], multiples of 64")
+            arr[i] = _MhTransposeJob(src.data_ptr(), dst.data_ptr(), rows, cols)
+            items += [(i << 32) | t for t in range((rows // 64) * (cols // 64))]
+            self.keep += [src, dst]
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        self.items = torch.tensor(items, dtype=torch.int64).to(device)
+        self.n_items = len(items)
+
+    def launch(self) -> None:
+        call("mh_transpose_u8_batched", self.table, self.items, _I(self.n_items))
 
 
 class QuantBatch:

@@ -108,12 +108,16 @@ COMMON = dict(interpolate="nearest", model="mae", num_levels=1, type_head="atten
 # fp8 forward (e4m3, 3 mantissa bits) against the fp32 oracle: observed on MI355X (round 2) loss 4.2e-4, pixels_rec 5.6e-2,
 # worst parameter gradient 8.6e-2 (relative L2) -- tolerances <= 3x; the bf16 engine sits at 3.5e-4 / 7e-3 / 1.5e-2
 FP8_LOSS_TOL, FP8_PIX_TOL, FP8_GRAD_TOL = 1.2e-3, 1.5e-1, 2.5e-1
+FP8_DGRAD_TOL = 0.3    # opt-in e5m2 data-gradient GEMMs (2 mantissa bits): observed worst 0.104
 
 
-def test_engine_fp8_forward_matches_oracle(dev, observed):
+@pytest.mark.parametrize("dgrad", ["0", "1"])
+def test_engine_fp8_forward_matches_oracle(dev, observed, monkeypatch, dgrad):
     """The whole step with e4m3 forward GEMMs (maestro_amd/fp8.py) against the fp32 oracle, same weights / inputs / draws:
     masks bit-exact, loss, reconstructions and every parameter gradient within the stated fp8 tolerances; a second forward
-    (scales now derived from the first step's absmax) stays as close; one AdamW step refreshes the e4m3 weight shadows."""
+    (scales now derived from the first step's absmax) stays as close; one AdamW step refreshes the e4m3 weight shadows.
+    ``dgrad`` 1: the opt-in e5m2 data-gradient GEMMs (``MAESTRO_FP8_DGRAD``), checked on the second backward."""
+    monkeypatch.setenv("MAESTRO_FP8_DGRAD", dgrad)
     import maestro_amd.conf as conf
     from maestro_amd.ssl import mae as pmae
     from maestro_amd.train.optim import FusedAdamW
@@ -154,16 +158,21 @@ def test_engine_fp8_forward_matches_oracle(dev, observed):
     assert e < FP8_LOSS_TOL, (loss.item(), oloss.item())
     ograds = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
     gmax = max(g.abs().max().item() for g in ograds.values())
-    worst = (0.0, None)
-    for k, p in model.named_parameters():
-        if k in ograds:
-            got, want = eng.store.g(p).cpu(), ograds[k]
-            err, ref = (got - want).double().norm().item(), want.double().norm().item()
-            floor = 1e-4 * gmax * want.numel() ** 0.5
-            if ref > 10 * floor and err / ref > worst[0]:
-                worst = (err / ref, k)
-            assert err <= FP8_GRAD_TOL * ref + floor, (k, err / max(ref, 1e-12))
-    observed("fp8/small", f"grad_worst/{worst[1]}", worst[0])
+
+    def check_grads(tag, tol):
+        worst = (0.0, None)
+        for k, p in model.named_parameters():
+            if k in ograds:
+                got, want = eng.store.g(p).cpu(), ograds[k]
+                err, ref = (got - want).double().norm().item(), want.double().norm().item()
+                floor = 1e-4 * gmax * want.numel() ** 0.5
+                if ref > 10 * floor and err / ref > worst[0]:
+                    worst = (err / ref, k)
+                assert err <= tol * ref + floor, (tag, k, err / max(ref, 1e-12))
+        observed("fp8/small", f"{tag}/{worst[1]}", worst[0])
+
+    assert eng.fp8.dgrad == (dgrad == "1") and (not eng.fp8.dgrad or all(f["dgrad"] for st in eng._all_stacks() for f in st.f8))
+    check_grads("grad_worst", FP8_GRAD_TOL)          # (first backward: bf16 dgrads, the e5m2 gradient scales are being calibrated)
     # second forward: activation scales are now derived from the first step's absmax (delayed scaling)
     assert float(eng.fp8.asc.scale.max()) > 1.0 or float(eng.fp8.asc.scale.min()) < 1.0
     loss2 = eng.forward(dbatch, noise=noise, struct=struct).clone()
@@ -175,6 +184,13 @@ def test_engine_fp8_forward_matches_oracle(dev, observed):
     w8_before = eng.enc["aerial"].f8[0]["w_qkv"].clone()
     eng.zero_grad()
     eng.backward()
+    if eng.fp8.dgrad:
+        # second backward, same weights and draws: the four dgrads of every layer now run e5m2 gradients x transposed e4m3
+        # weights with the scales calibrated by the first one
+        assert eng.fp8.grad_ready and float(eng.fp8.gsc.scale.min()) > 1.0
+        f0 = eng.enc["aerial"].f8[0]
+        assert torch.equal(f0["wt_fc1"], f0["w_fc1"].t().contiguous()) and torch.equal(f0["wt_qkv"], f0["w_qkv"].t().contiguous())
+        check_grads("grad_worst_fp8_dgrad", FP8_DGRAD_TOL)
     FusedAdamW(eng, 1e-3).step()
     loss3 = eng.forward(dbatch, noise=noise, struct=struct).clone()
     torch.cuda.synchronize()
@@ -241,3 +257,49 @@ def test_adamw_fp8_refreshes_the_shadows_in_its_own_pass(dev):
         want = _q((p_new[lo:hi] * sc).clamp(-448, 448), 0).view(torch.uint8)
         assert torch.equal(p8[lo:hi], want) and float(amax[slot].max()) == float(p_new[lo:hi].abs().max())
     assert bool((p8[: 4 * 64] == 7).all()) and bool((p8[20 * 64: 24 * 64] == 7).all())
+
+
+def test_transpose_u8_batched(dev):
+    """``mh_transpose_u8_batched`` (transposed e4m3 weight shadows for the fp8 dgrad): byte-exact for several shapes in one launch."""
+    from maestro_amd import hip
+    g = torch.Generator().manual_seed(4)
+    shapes = [(64, 64), (768, 3072), (2304, 768), (512, 128)]
+    srcs = [torch.randint(0, 256, s, generator=g, dtype=torch.uint8).to(dev) for s in shapes]
+    dsts = [torch.zeros(s[1], s[0], dtype=torch.uint8, device=dev) for s in shapes]
+    hip.TransposeBatch(list(zip(srcs, dsts)), dev).launch()
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(d.cpu(), s.cpu().t().contiguous())
+    with pytest.raises(hip.HipExtensionError):
+        hip.TransposeBatch([(torch.zeros(65, 64, dtype=torch.uint8, device=dev), torch.zeros(64, 65, dtype=torch.uint8, device=dev))], dev)
+
+
+def test_gemm_fp8_dgrad_epilogue(dev):
+    """The dgrad form of ``mh_gemm_fp8``: e5m2 A operand x e4m3 B, ``MULAUX | COLSUM`` epilogue and an e5m2 copy of the output
+    (``MH_GEMM_C8_E5M2``) -- against the bf16 kernel on the same (fp8-representable) operands."""
+    from maestro_amd import hip
+    g = torch.Generator().manual_seed(6)
+    for (M, N, K) in ((320, 768, 384), (1000, 1536, 512)):   # noqa: N806
+        a = (torch.randn(M, K, generator=g) * 0.5).to(torch.float8_e5m2)
+        b = (torch.randn(N, K, generator=g) * 0.5).to(torch.float8_e4m3fn)
+        aux = (torch.rand(M, N, generator=g) * 1.2 - 0.1).to(torch.bfloat16).to(dev)
+        A8, B8 = a.view(torch.uint8).to(dev), b.view(torch.uint8).to(dev)   # noqa: N806
+        A16, B16 = a.float().to(torch.bfloat16).to(dev), b.float().to(torch.bfloat16).to(dev)   # noqa: N806 -- exact in bf16
+        rows = (M + 63) // 64
+        C8, C16 = (torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(2))  # noqa: N806
+        cs8, cs16 = torch.zeros(rows, N, device=dev), torch.zeros(rows, N, device=dev)
+        c8, s8, amax = torch.zeros(M, N, dtype=torch.uint8, device=dev), torch.tensor([64.0], device=dev), torch.zeros(hip.AMAX_PITCH, device=dev)
+        one = torch.ones(1, device=dev)
+        fl = hip.MULAUX | hip.COLSUM
+        hip.gemm_fp8(M, N, K, A8, K, B8, K, C8, N, one, one, flags=fl | hip.C8_E5M2, a_format=hip.FP8_E5M2, aux_in=aux, ldaux=N,
+                     colsum=cs8, c8=c8, ldc8=N, c8_scale=s8, c8_amax=amax)
+        hip.gemm(hip.GEMM_NT, M, N, K, A16, K, B16, K, C16, N, fl, aux_in=aux, ldaux=N, colsum=cs16)
+        torch.cuda.synchronize()
+        assert (C8.float() - C16.float()).abs().max() <= 2e-2 * C16.float().abs().max()
+        assert (C8.float() - C16.float()).abs().mean() < 1e-4 * C16.float().abs().max()
+        assert (cs8 - cs16).abs().max() < 1e-3 * cs16.abs().max()
+        lim = 57344.0
+        want = (C8.float() * 64.0).clamp(-lim, lim).to(torch.float8_e5m2).view(torch.uint8).int()
+        diff = (c8.int() - want).abs()          # the copy is cast from the fp32 value, the comparison from its bf16 rounding
+        assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 0.1
+        assert abs(float(amax.max()) - float(C8.float().abs().max())) <= 2 ** -7 * float(amax.max())
