@@ -207,6 +207,13 @@ int mh_attn_bwd(const void* qkv, const void* out, const void* dout, const float*
  * rescale_elev (maestro/ssl/mim.py:433-436): channels >= 1 become 30*(ch0 - ch) on the fly. */
 int mh_patchify(const float* img, void* cols, float* target, int BD, int Ctot, int S, int P, int Kpad,
                 const int* norm_bands, int n_norm_groups, int normalise, int rescale_elev, void* stream);
+/* The same for ONE band-group of a modality with several (Patchify splits the channel axis by group sizes and gives every
+ * group its own PatchifyBands conv, maestro/layers/embed.py:18-34): img f32 [BD, Csrc, S, S], the patch takes channels
+ * c0 .. c0 + Ctot - 1; rescale_elev refers to channel 0 of the image.  cols or target may be NULL (the loss target of such a
+ * modality is built once over ALL its channels -- the norm_bands groups of maestro/train/model.py:219-229 ignore the band-
+ * groups -- with cols == NULL, c0 = 0, Ctot = Csrc). */
+int mh_patchify_bands(const float* img, void* cols, float* target, int BD, int Csrc, int c0, int Ctot, int S, int P, int Kpad,
+                      const int* norm_bands, int n_norm_groups, int normalise, int rescale_elev, void* stream);
 
 /* GroupNorm(1, E) over the whole (tokens x E) image per (b, d) (embed.py:55,59-61): chunked partial sums ->
  * stats f32 [BD, 2] = (mean, rstd).  partial: f32 workspace of mh_groupnorm_partial_size() floats. */
@@ -272,6 +279,9 @@ int mh_unmask_token_grad(const float* dxdec, const uint8_t* mask, const int* tok
                          int Dd, int slot, int t_lo, int t_hi, void* stream);
 /* out[0] = number of masked tokens of all samples in group positions [t_lo, t_hi) (one modality). */
 int mh_count_masked(const uint8_t* mask, int B, int L, int t_lo, int t_hi, int* out, void* stream);
+/* out[0] = (accumulate ? out[0] : 0) + mult * that count: the masked ELEMENTS of a modality whose band-groups have different
+ * patch sizes in elements (mult = P*P*bands of the group); the denominator of mh_masked_loss_bands. */
+int mh_count_masked_elems(const uint8_t* mask, int B, int L, int t_lo, int t_hi, int* out, int mult, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- loss
  * Masked reconstruction loss at patch layout (maestro/train/model.py:195-247) for one modality: rec f32 [B*Lm, PPC]
@@ -281,6 +291,13 @@ int mh_count_masked(const uint8_t* mask, int B, int L, int t_lo, int t_hi, int* 
  *   drec (bf16 [B*Lm, PPC], optional) = coef * d e / d rec on masked tokens, 0 elsewhere. */
 int mh_masked_loss(const float* rec, const float* target, const uint8_t* mask_group, const int* n_masked, float weight,
                    float* acc, void* drec, int B, int Lm, int Lgroup, int tok_off, int PPC, int p, void* stream);
+/* One band-group of a modality with several (Pixelify concatenates the groups' reconstructions along the channel axis and
+ * the loss is ONE mean over the modality's masked elements, maestro/layers/embed.py:99-127, maestro/train/model.py:241-243):
+ * rec f32 [B*Lm, PPC] with PPC = P*P*n_g, columns pixel * n_g + c; target = the MODALITY's rows [B*Lm, P*P*tgt_C], the group
+ * reads columns pixel * tgt_C + tgt_c0 + c; coef = weight / n_elems[0] (mh_count_masked_elems over all groups). */
+int mh_masked_loss_bands(const float* rec, const float* target, const uint8_t* mask_group, const int* n_elems, float weight,
+                         float* acc, void* drec, int B, int Lm, int Lgroup, int tok_off, int PPC, int p, int tgt_C, int tgt_c0,
+                         int n_g, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- probe / finetune heads
  * (maestro/ssl/mim.py:343-394 compute_logits, maestro/layers/head.py, maestro/train/base.py:98-151)

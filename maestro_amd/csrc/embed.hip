@@ -21,16 +21,19 @@ __device__ __forceinline__ float block_sum_any(float v, float* red) {
 }
 
 // One block per patch (token).  LDS holds the patch in TARGET order [(p1*P+p2)*Ctot + c].
+// Band windows (several band-groups per modality, maestro/layers/embed.py:18-34): the image has Csrc channels, the patch takes
+// channels c0 .. c0 + Ctot - 1 of it; the elevation rescale always refers to channel 0 of the IMAGE.
 __global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ cols, float* __restrict__ target,
-                                int Ctot, int S, int P, int Kpad, const int* __restrict__ norm_bands, int n_groups,
-                                int normalise, int rescale_elev) {
+                                int Csrc, int c0, int Ctot, int S, int P, int Kpad, const int* __restrict__ norm_bands,
+                                int n_groups, int normalise, int rescale_elev) {
     extern __shared__ __attribute__((aligned(16))) float patch[];  // P*P*Ctot floats + 8 reduction slots
     const int g = S / P;
     const int tok = blockIdx.x;  // (bd, ph, pw)
     const int bd = tok / (g * g), pp = tok - bd * g * g, ph = pp / g, pw = pp - ph * g;
     const int PP = P * P, K = Ctot * PP;
     float* red = patch + K;
-    const float* base = img + ((size_t)bd * Ctot) * S * S + (size_t)(ph * P) * S + pw * P;
+    const float* base0 = img + ((size_t)bd * Csrc) * S * S + (size_t)(ph * P) * S + pw * P;   // channel 0 of the image
+    const float* base = base0 + (size_t)c0 * S * S;
     if ((P & 3) == 0 && (Kpad & 3) == 0) {
         // four consecutive pixels of one patch row per thread: 16-byte image loads, 8-byte bf16 stores
         for (int k = threadIdx.x * 4; k < Kpad; k += blockDim.x * 4) {
@@ -38,12 +41,14 @@ __global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restric
             if (k < K) {
                 const int c = k / PP, r = k - c * PP, p1 = r / P, p2 = r - p1 * P;
                 v = *reinterpret_cast<const f32x4*>(base + (size_t)c * S * S + p1 * S + p2);
-                if (rescale_elev && c >= 1) v = 30.f * (*reinterpret_cast<const f32x4*>(base + p1 * S + p2) - v);
+                if (rescale_elev && c0 + c >= 1) v = 30.f * (*reinterpret_cast<const f32x4*>(base0 + p1 * S + p2) - v);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) patch[(r + e) * Ctot + c] = v[e];
             }
-            u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(cols + (size_t)tok * Kpad + k) = pk;
+            if (cols) {
+                u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(cols + (size_t)tok * Kpad + k) = pk;
+            }
         }
     } else {
         for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
@@ -51,10 +56,10 @@ __global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restric
             if (k < K) {
                 const int c = k / PP, r = k - c * PP, p1 = r / P, p2 = r - p1 * P;
                 v = base[(size_t)c * S * S + p1 * S + p2];
-                if (rescale_elev && c >= 1) v = 30.f * (base[p1 * S + p2] - v);
+                if (rescale_elev && c0 + c >= 1) v = 30.f * (base0[p1 * S + p2] - v);
                 patch[r * Ctot + c] = v;
             }
-            cols[(size_t)tok * Kpad + k] = f2bf(v);
+            if (cols) cols[(size_t)tok * Kpad + k] = f2bf(v);
         }
     }
     if (!target) return;
@@ -396,7 +401,16 @@ extern "C" int mh_rescale_elev(const float* img, float* out, int BD, int C, int 
 
 extern "C" int mh_patchify(const float* img, void* cols, float* target, int BD, int Ctot, int S, int P, int Kpad,
                            const int* norm_bands, int n_norm_groups, int normalise, int rescale_elev, void* stream) {
-    MH_CHECK_ARG(img && cols, "mh_patchify: null pointer");
+    MH_CHECK_ARG(cols, "mh_patchify: null pointer");
+    return mh_patchify_bands(img, cols, target, BD, Ctot, 0, Ctot, S, P, Kpad, norm_bands, n_norm_groups, normalise, rescale_elev,
+                             stream);
+}
+
+extern "C" int mh_patchify_bands(const float* img, void* cols, float* target, int BD, int Csrc, int c0, int Ctot, int S, int P,
+                                 int Kpad, const int* norm_bands, int n_norm_groups, int normalise, int rescale_elev,
+                                 void* stream) {
+    MH_CHECK_ARG(img && (cols || target), "mh_patchify: null pointer");
+    MH_CHECK_ARG(c0 >= 0 && Ctot > 0 && c0 + Ctot <= Csrc, "mh_patchify_bands: band window [%d, %d) outside %d channels", c0, c0 + Ctot, Csrc);
     MH_CHECK_ARG(S % P == 0 && Kpad >= Ctot * P * P && Kpad % 8 == 0, "mh_patchify: bad geometry S=%d P=%d Kpad=%d", S, P, Kpad);
     MH_CHECK_ARG(!normalise || !target || (norm_bands && n_norm_groups > 0), "mh_patchify: norm_bands missing");
     const int K = Ctot * P * P, g = S / P;
@@ -404,7 +418,7 @@ extern "C" int mh_patchify(const float* img, void* cols, float* target, int BD, 
     const size_t lds = (size_t)(K + 8) * sizeof(float);
     MH_CHECK_ARG(lds <= 64 * 1024, "mh_patchify: patch too large for LDS (%d floats)", K);
     hipLaunchKernelGGL(patchify_kernel, dim3(BD * g * g), dim3(threads), lds, (hipStream_t)stream, img, (bf16_t*)cols,
-                       target, Ctot, S, P, Kpad, norm_bands, n_norm_groups, normalise, rescale_elev);
+                       target, Csrc, c0, Ctot, S, P, Kpad, norm_bands, n_norm_groups, normalise, rescale_elev);
     MH_LAUNCH_CHECK();
     return 0;
 }

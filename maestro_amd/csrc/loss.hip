@@ -11,23 +11,34 @@ namespace {
 __global__ __launch_bounds__(256) void masked_loss_kernel(const float* __restrict__ rec, const float* __restrict__ target,
                                                           const uint8_t* __restrict__ mask_group, const int* __restrict__ n_masked,
                                                           float weight, float* __restrict__ acc, bf16_t* __restrict__ drec,
-                                                          int B, int Lm, int Lgroup, int tok_off, int PPC, int p) {
+                                                          int B, int Lm, int Lgroup, int tok_off, int PPC, int p, int tgt_C,
+                                                          int tgt_c0, int n_g, int denom_is_elems) {
+    // band window (several band-groups per modality): rec column k = pixel * n_g + c pairs with target column
+    // pixel * tgt_C + tgt_c0 + c of the MODALITY's target rows (tgt_C channels); n_g == tgt_C: the plain case
     __shared__ float red[4];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + w;
-    const float coef = weight / ((float)(*n_masked) * (float)PPC);
+    const float coef = weight / (denom_is_elems ? (float)(*n_masked) : (float)(*n_masked) * (float)PPC);
+    const bool window = n_g != tgt_C;
+    const int tgt_ld = window ? PPC / n_g * tgt_C : PPC;
     float s = 0.f;
     if (row < B * Lm) {
         const int b = row / Lm, t = row - b * Lm;
         const bool masked = mask_group[(size_t)b * Lgroup + tok_off + t] != 0;
         const float* r = rec + (size_t)row * PPC;
-        const float* g = target + (size_t)row * PPC;
+        const float* g = target + (size_t)row * tgt_ld;
         bf16_t* d = drec ? drec + (size_t)row * PPC : nullptr;
         for (int c = lane * 4; c < PPC; c += 256) {
             float dd[4] = {0.f, 0.f, 0.f, 0.f};
             if (masked) {
                 const f32x4 rv = *reinterpret_cast<const f32x4*>(r + c);
-                const f32x4 tv = *reinterpret_cast<const f32x4*>(g + c);
+                f32x4 tv;
+                if (!window) {
+                    tv = *reinterpret_cast<const f32x4*>(g + c);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const int pix = (c + e) / n_g; tv[e] = g[pix * tgt_C + tgt_c0 + (c + e) - pix * n_g]; }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float diff = rv[e] - tv[e];
@@ -237,7 +248,20 @@ extern "C" int mh_masked_loss(const float* rec, const float* target, const uint8
     MH_CHECK_ARG(rec && target && mask_group && n_masked && acc, "mh_masked_loss: null pointer");
     MH_CHECK_ARG((p == 1 || p == 2) && PPC % 4 == 0 && tok_off + Lm <= Lgroup, "mh_masked_loss: bad arguments");
     hipLaunchKernelGGL(masked_loss_kernel, dim3(ceil_div((long)B * Lm, 4)), dim3(256), 0, (hipStream_t)stream, rec, target, mask_group, n_masked,
-                       weight, acc, (bf16_t*)drec, B, Lm, Lgroup, tok_off, PPC, p);
+                       weight, acc, (bf16_t*)drec, B, Lm, Lgroup, tok_off, PPC, p, 1, 0, 1, 0);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_masked_loss_bands(const float* rec, const float* target, const uint8_t* mask_group, const int* n_elems,
+                                    float weight, float* acc, void* drec, int B, int Lm, int Lgroup, int tok_off, int PPC, int p,
+                                    int tgt_C, int tgt_c0, int n_g, void* stream) {
+    MH_CHECK_ARG(rec && target && mask_group && n_elems && acc, "mh_masked_loss_bands: null pointer");
+    MH_CHECK_ARG((p == 1 || p == 2) && PPC % 4 == 0 && tok_off + Lm <= Lgroup, "mh_masked_loss_bands: bad arguments");
+    MH_CHECK_ARG(n_g > 0 && PPC % n_g == 0 && tgt_c0 >= 0 && tgt_c0 + n_g <= tgt_C, "mh_masked_loss_bands: band window [%d, %d) of %d",
+                 tgt_c0, tgt_c0 + n_g, tgt_C);
+    hipLaunchKernelGGL(masked_loss_kernel, dim3(ceil_div((long)B * Lm, 4)), dim3(256), 0, (hipStream_t)stream, rec, target, mask_group, n_elems,
+                       weight, acc, (bf16_t*)drec, B, Lm, Lgroup, tok_off, PPC, p, tgt_C, tgt_c0, n_g, 1);
     MH_LAUNCH_CHECK();
     return 0;
 }

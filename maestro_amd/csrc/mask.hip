@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void unmask_bwd_token_kernel(const float* __re
 }
 
 __global__ __launch_bounds__(1024) void count_masked_kernel(const uint8_t* __restrict__ mask, int B, int L, int t_lo, int t_hi,
-                                                            int* __restrict__ out) {
+                                                            int* __restrict__ out, int mult, int accumulate) {
     // one block, 16 waves: wave w walks rows w, w + 16, ... with 64 consecutive bytes per load instruction (independent
     // loads, no index division); a single 256-thread block with a divide per element took 41 us for 32 x 1024 tokens
     __shared__ float red[16];
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(1024) void count_masked_kernel(const uint8_t* __res
         for (int t = lane; t < span; t += 64) c += row[t] ? 1.f : 0.f;
     }
     c = block_sum<16>(c, red);
-    if (threadIdx.x == 0) *out = (int)(c + 0.5f);
+    if (threadIdx.x == 0) *out = (accumulate ? *out : 0) + (int)(c + 0.5f) * mult;
 }
 
 }  // namespace
@@ -218,9 +218,18 @@ extern "C" int mh_unmask_token_grad(const float* dxdec, const uint8_t* mask, con
     return 0;
 }
 
+extern "C" int mh_count_masked_elems(const uint8_t* mask, int B, int L, int t_lo, int t_hi, int* out, int mult, int accumulate,
+                                     void* stream) {
+    MH_CHECK_ARG(mask && out && 0 <= t_lo && t_lo < t_hi && t_hi <= L && mult > 0, "mh_count_masked_elems: bad arguments");
+    hipLaunchKernelGGL(count_masked_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, L, t_lo, t_hi, out, mult,
+                       accumulate);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int mh_count_masked(const uint8_t* mask, int B, int L, int t_lo, int t_hi, int* out, void* stream) {
     MH_CHECK_ARG(mask && out && 0 <= t_lo && t_lo < t_hi && t_hi <= L, "mh_count_masked: bad arguments");
-    hipLaunchKernelGGL(count_masked_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, L, t_lo, t_hi, out);
+    hipLaunchKernelGGL(count_masked_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, L, t_lo, t_hi, out, 1, 0);
     MH_LAUNCH_CHECK();
     return 0;
 }

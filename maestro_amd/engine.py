@@ -718,14 +718,17 @@ class MAEEngine(EngineBase):
         for name, s in self.mods.items():
             T = s.Beff * s.n_tok  # noqa: N806
             BD = s.Beff * s.D  # noqa: N806
-            pe = m.patch_embed[s.embed].patchify_bands[0]
+            pe = m.patch_embed[s.embed].patchify_bands[s.gi]
+            # a modality with several band-groups: ONE loss target over all its channels (the norm_bands groups of
+            # model.py:219-229 ignore the band-groups) and one masked-element count, owned by band-group 0, shared by the rest
+            first = self.mb[m.src_specs[s.src][0].name] if s.gi else None
             self.mb[name] = dict(
-                cols=e(T, s.Kpad, dt=BF16), target=e(T, s.K), yconv=e(T, E),
+                cols=e(T, s.Kpad, dt=BF16), target=first["target"] if first else e(T, s.C_src * s.P * s.P), yconv=e(T, E),
                 gn_partial=e(hip.groupnorm_partial_size(BD, s.L, E)), gn_stats=e(BD, 2), gn_sums=e(BD, 2),
                 pos_enc=m.pos_enc_rows[name].to(dev), norm_bands=torch.tensor(s.norm_bands, dtype=I32, device=dev),
                 w_conv16=z(E, s.Kpad, dt=BF16), dw_conv=z(E, s.Kpad), dyc=e(T, E, dt=BF16),
                 hdec=e(T, Dd, dt=BF16), mean_f=e(T), rstd_f=e(T), rec=e(T, s.K), drec=e(T, s.K, dt=BF16),
-                dh=e(T, Dd, dt=BF16), cnt=z(1, dt=I32), pe=pe)
+                dh=e(T, Dd, dt=BF16), cnt=first["cnt"] if first else z(1, dt=I32), pe=pe)
         self.gb = {}
         self.enc, self.dec = {}, {}
         for g in self.groups:
@@ -769,8 +772,9 @@ class MAEEngine(EngineBase):
             self.gb[g.name]["ln_ws"] = e(max(hip.layernorm_bwd_workspace(g.Beff * g.L, Dd),
                                              hip.layernorm_bwd_workspace(g.Beff * g.N, E)))
         self.loss_acc = z(1)
-        tot_w = sum(s.Dates * s.L for s in self.mods.values())
-        self.loss_w = {n: (s.Dates * s.L) / tot_w for n, s in self.mods.items()}  # weight = D*H*W (model.py:239)
+        srcs = {s.src: s for s in self.mods.values()}            # weight = D*H*W per MODALITY (model.py:239), band-groups share it
+        tot_w = sum(s.Dates * s.L for s in srcs.values())
+        self.loss_w = {n: (s.Dates * s.L) / tot_w for n, s in srcs.items()}
 
     def _pack_conv_weights(self, fp8_done: bool = False) -> None:
         """Derived weight copies beyond the flat bf16 shadow (called wherever the shadows are refreshed: engine start,
@@ -827,13 +831,14 @@ class MAEEngine(EngineBase):
         ev = torch.cuda.Event()
         ev.record()
         self._h2d_done[slot] = ev
-        for s in self.mods.values():
-            img = batch[s.name]
+        sources = [parts[0] for parts in self.model.src_specs.values()]      # one spec per batch entry (band-group 0)
+        for s in sources:
+            img = batch[s.src]
             if img.dtype != F32 or not img.is_contiguous() or not img.is_cuda:
-                raise ValueError(f"batch[{s.name!r}] must be a contiguous float32 GPU tensor")
+                raise ValueError(f"batch[{s.src!r}] must be a contiguous float32 GPU tensor")
         batch = self._stable_inputs(batch)
-        for s in self.mods.values():
-            img = batch[s.name]
+        for s in sources:
+            img = batch[s.src]
             if tuple(img.shape[-2:]) != (s.S, s.S) or self.model.interpolate != "nearest":
                 # input staging (mim.py:427-432): resize to image_size on the GPU into an engine-owned buffer
                 mode = {"nearest": 0, "bilinear": 1, "bicubic": 2}.get(self.model.interpolate)
@@ -841,12 +846,12 @@ class MAEEngine(EngineBase):
                     raise ValueError(f"Invalid interpolate mode {self.model.interpolate!r} (nearest, bilinear, bicubic)")
                 buf = self.mb[s.name].get("resized")
                 if buf is None:
-                    buf = self.mb[s.name]["resized"] = torch.empty(self.B, s.Dates, s.C, s.S, s.S, dtype=F32, device=self.device)
-                hip.resize(img, buf, self.B * s.Dates * s.C, img.shape[-2], img.shape[-1], s.S, s.S, mode)
-                batch[s.name] = buf
-            d = batch[f"{s.name}_dates"]
+                    buf = self.mb[s.name]["resized"] = torch.empty(self.B, s.Dates, s.C_src, s.S, s.S, dtype=F32, device=self.device)
+                hip.resize(img, buf, self.B * s.Dates * s.C_src, img.shape[-2], img.shape[-1], s.S, s.S, mode)
+                batch[s.src] = buf
+            d = batch[f"{s.src}_dates"]
             if d.dtype != torch.int16 or not d.is_contiguous():
-                raise ValueError(f"batch['{s.name}_dates'] must be a contiguous int16 tensor [B, D, 3]")
+                raise ValueError(f"batch['{s.src}_dates'] must be a contiguous int16 tensor [B, D, 3]")
         self._staged = batch
         key = self._cur_key = tuple(batch[k].data_ptr() for k in sorted(batch) if isinstance(batch[k], torch.Tensor))
         with self._tuning_pass("forward"):
@@ -968,9 +973,18 @@ class MAEEngine(EngineBase):
                 for s in g.mods:
                     b = self.mb[s.name]
                     BD = s.Beff * s.D  # noqa: N806
-                    hip.patchify(batch[s.name], b["cols"], b["target"], BD, s.C, s.S, s.P, s.Kpad, b["norm_bands"],
-                                 len(s.norm_bands), self.normalise, s.rescale_elev)
-                    dates = batch[f"{s.name}_dates"]
+                    if s.G == 1:
+                        hip.patchify(batch[s.name], b["cols"], b["target"], BD, s.C, s.S, s.P, s.Kpad, b["norm_bands"],
+                                     len(s.norm_bands), self.normalise, s.rescale_elev)
+                    else:   # one band-group: its channel window for the conv; the modality's target once, over all channels
+                        hip.patchify_bands(batch[s.src], b["cols"], None, BD, s.C_src, s.c0, s.C, s.S, s.P, s.Kpad, None, 0, False,
+                                           s.rescale_elev)
+                        if s.gi == 0:
+                            k_src = s.C_src * s.P * s.P
+                            hip.patchify_bands(batch[s.src], None, b["target"], BD, s.C_src, 0, s.C_src, s.S, s.P,
+                                               (k_src + 7) // 8 * 8, b["norm_bands"], len(s.norm_bands), self.normalise,
+                                               s.rescale_elev)
+                    dates = batch[f"{s.src}_dates"]
                     if s.D != s.Dates:   # dates folded into the batch: one date row per sequence
                         hip.date_features(dates, ref_date, gbuf["dates"].view(self.B, s.Dates, 8), self.B, s.Dates, s.Dates,
                                           0, m.fac_date_enc)
@@ -1021,7 +1035,7 @@ class MAEEngine(EngineBase):
                     hip.gemm(hip.GEMM_NT, M, Dd, E, gbuf["henc"], E, self.store.h(lin.weight), E, gbuf["y_e2d"], Dd,
                              hip.OUT_F32 | hip.BIAS, bias=lin.bias)
                 for s in g.mods:
-                    gbuf["tok_table"][s.slot].copy_(m.mask_token[s.name].view(-1))
+                    gbuf["tok_table"][s.slot].copy_(m.mask_token[s.src].view(s.G, Dd)[s.gi])
                 hip.unmask_assemble(gbuf["y_e2d"], gbuf["inv"], gbuf["tok_table"], gbuf["tok_slot"], gbuf["pos_dec"],
                                     gbuf["dates"], gbuf["date_row"], gbuf["n_dates"], st.x0, g.Beff, g.L, g.N, Dd)
                 if part == "pre":
@@ -1036,14 +1050,23 @@ class MAEEngine(EngineBase):
             for s in g.mods:
                 b = self.mb[s.name]
                 T = s.Beff * s.n_tok  # noqa: N806
-                conv = m.embed_to_rec[s.embed].pixelify_bands[0].conv
+                conv = m.embed_to_rec[s.embed].pixelify_bands[s.gi].conv
                 hip.layernorm_fwd(st.x_last, g.L, s.tok_off, nrm.weight, nrm.bias, b["hdec"], s.n_tok, 0, b["mean_f"],
                                   b["rstd_f"], s.Beff, s.n_tok, Dd)
                 hip.gemm(hip.GEMM_NT, T, s.K, Dd, b["hdec"], Dd, self.store.h(conv.weight).view(s.K, Dd), Dd, b["rec"],
                          s.K, hip.OUT_F32 | hip.BIAS, bias=conv.bias)
-                hip.count_masked(gbuf["mask"], g.Beff, g.L, s.tok_off, s.tok_off + s.n_tok, b["cnt"])
-                hip.masked_loss(b["rec"], b["target"], gbuf["mask"], b["cnt"], self.loss_w[s.name], self.loss_acc,
-                                b["drec"], s.Beff, s.n_tok, g.L, s.tok_off, s.K, self.p_loss)
+                if s.G == 1:
+                    hip.count_masked(gbuf["mask"], g.Beff, g.L, s.tok_off, s.tok_off + s.n_tok, b["cnt"])
+                else:       # masked ELEMENTS of the whole modality (its band-groups have different patch sizes in elements)
+                    hip.count_masked_elems(gbuf["mask"], g.Beff, g.L, s.tok_off, s.tok_off + s.n_tok, b["cnt"], s.K, s.gi > 0)
+            for s in g.mods:    # (after every band-group's count: the loss of a modality is ONE mean over its masked elements)
+                b = self.mb[s.name]
+                if s.G == 1:
+                    hip.masked_loss(b["rec"], b["target"], gbuf["mask"], b["cnt"], self.loss_w[s.src], self.loss_acc,
+                                    b["drec"], s.Beff, s.n_tok, g.L, s.tok_off, s.K, self.p_loss)
+                else:
+                    hip.masked_loss_bands(b["rec"], b["target"], gbuf["mask"], b["cnt"], self.loss_w[s.src], self.loss_acc,
+                                          b["drec"], s.Beff, s.n_tok, g.L, s.tok_off, s.K, self.p_loss, s.C_src, s.c0, s.C)
 
         if self.enc_set is not None:     # embed / mask per group (parallel streams), the encoders in lockstep, final LNs
             self._run_parallel([head(g, "pre") for g in self.groups])
@@ -1196,7 +1219,7 @@ class MAEEngine(EngineBase):
                 for s in g.mods:
                     b = self.mb[s.name]
                     T = s.Beff * s.n_tok  # noqa: N806
-                    conv = m.embed_to_rec[s.embed].pixelify_bands[0].conv
+                    conv = m.embed_to_rec[s.embed].pixelify_bands[s.gi].conv
                     w16 = ps.h(conv.weight).view(s.K, Dd)
                     hip.gemm(hip.GEMM_NN, T, Dd, s.K, b["drec"], s.K, w16, Dd, b["dh"], Dd)
                     hip.gemm(hip.GEMM_TN, s.K, Dd, T, b["drec"], s.K, b["hdec"], Dd, ps.g(conv.weight).view(s.K, Dd), Dd, AT)
@@ -1216,9 +1239,9 @@ class MAEEngine(EngineBase):
             # unmask backward: visible rows -> enc_to_dec output grad; masked rows -> mask-token grads
             hip.gather_rows(dx0, gbuf["vis"], gbuf["dy_e2d"], g.Beff, g.L, g.N, Dd, g.N, 0)
             for s in g.mods:
-                hip.unmask_token_grad(dx0, gbuf["mask"], gbuf["tok_slot"], ps.g(m.mask_token[s.name]).view(-1), g.Beff,
+                hip.unmask_token_grad(dx0, gbuf["mask"], gbuf["tok_slot"], ps.g(m.mask_token[s.src]).view(s.G, Dd)[s.gi], g.Beff,
                                       g.L, Dd, s.slot, s.tok_off, s.tok_off + s.n_tok)
-                self._ready_spans.append(ps.span([m.mask_token[s.name]]))
+                self._ready_spans.append(ps.span([m.mask_token[s.src]]))
             M = g.Beff * g.N  # noqa: N806
             lin = m.enc_to_dec[g.model]
             if not self.e2d_identity:
@@ -1338,37 +1361,46 @@ class MAEEngine(EngineBase):
                 pixels[s.name] = img.view(self.B, s.Dates, s.C, s.S, s.S)
                 tok = mask[:, s.tok_off: s.tok_off + s.n_tok].bool().reshape(self.B, s.Dates, 1, s.g, 1, s.g, 1)
                 masks[s.name] = tok.expand(self.B, s.Dates, s.C, s.g, s.P, s.g, s.P).reshape(self.B, s.Dates, s.C, s.S, s.S)
+        # a modality with several band-groups: Pixelify concatenates the groups' outputs on the channel axis (embed.py:112-114)
+        for src, parts in self.model.src_specs.items():
+            if len(parts) > 1:
+                pixels[src] = torch.cat([pixels.pop(s.name) for s in parts], dim=2)
+                masks[src] = torch.cat([masks.pop(s.name) for s in parts], dim=2)
         return pixels, masks
 
     def returned_batch(self, batch: dict) -> dict:
         """The reference returns the (in place) resized / elevation-rescaled batch (mim.py:425-437)."""
         out = dict(batch)
-        out.update({s.name: self._staged[s.name] for s in self.mods.values()})  # resized rasters (mim.py:427-432)
-        for s in self.mods.values():
+        sources = [parts[0] for parts in self.model.src_specs.values()]
+        out.update({s.src: self._staged[s.src] for s in sources})  # resized rasters (mim.py:427-432)
+        for s in sources:
             if s.rescale_elev:
-                img = out[s.name]
+                img = out[s.src]
                 res = torch.empty_like(img)
-                hip.rescale_elev(img, res, img.shape[0] * img.shape[1], s.C, s.S)
-                out[s.name] = res
+                hip.rescale_elev(img, res, img.shape[0] * img.shape[1], s.C_src, s.S)
+                out[s.src] = res
         return out
 
     def logged_sample(self, name_mod: str):
         """Sample ``[0, 0]`` of one modality for the image logs (``maestro/train/model.py:160-193`` keeps only that sample):
         ``(target, rec, mask)`` as ``[C, S, S]`` tensors -- the returned (resized, elevation-rescaled) batch, the
         reconstruction and the pixel-level mask.  Only that sample's L tokens are touched (a few tiny launches per step)."""
-        s = self.mods[name_mod]
-        g = next(g for g in self.groups if s in g.mods)
-        b = self.mb[name_mod]
-        rec = torch.empty(1, s.C, s.S, s.S, dtype=F32, device=self.device)
-        hip.depatchify(b["rec"][: s.L], rec, 1, s.C, s.S, s.P)           # tokens of (b = 0, d = 0) are rows [0, L)
+        parts = self.model.src_specs[name_mod]
+        s0 = parts[0]
+        recs, msks = [], []
+        for s in parts:                  # (several band-groups: channel-wise concatenation, as Pixelify does)
+            g = next(g for g in self.groups if s in g.mods)
+            rec = torch.empty(1, s.C, s.S, s.S, dtype=F32, device=self.device)
+            hip.depatchify(self.mb[s.name]["rec"][: s.L], rec, 1, s.C, s.S, s.P)    # tokens of (b = 0, d = 0) are rows [0, L)
+            tok = self.gb[g.name]["mask"][0, s.tok_off: s.tok_off + s.L].bool().reshape(1, s.g, 1, s.g, 1)
+            recs.append(rec[0])
+            msks.append(tok.expand(s.C, s.g, s.P, s.g, s.P).reshape(s.C, s.S, s.S))
         tgt = self._staged[name_mod][0, 0]
-        if s.rescale_elev:
-            res = torch.empty(1, s.C, s.S, s.S, dtype=F32, device=self.device)
-            hip.rescale_elev(tgt.contiguous(), res, 1, s.C, s.S)
+        if s0.rescale_elev:
+            res = torch.empty(1, s0.C_src, s0.S, s0.S, dtype=F32, device=self.device)
+            hip.rescale_elev(tgt.contiguous(), res, 1, s0.C_src, s0.S)
             tgt = res[0]
-        tok = self.gb[g.name]["mask"][0, s.tok_off: s.tok_off + s.L].bool().reshape(1, s.g, 1, s.g, 1)
-        msk = tok.expand(s.C, s.g, s.P, s.g, s.P).reshape(s.C, s.S, s.S)
-        return tgt, rec[0], msk
+        return tgt, (recs[0] if len(parts) == 1 else torch.cat(recs)), (msks[0] if len(parts) == 1 else torch.cat(msks))
 
     def token_masks(self) -> dict:
         """Per-group token masks ``{group: bool [Beff, L]}`` of the last forward."""

@@ -76,7 +76,7 @@ class SupervisedEngine(EngineBase):
         self.mb, self.gb, self.enc = {}, {}, {}
         for name, s in self.mods.items():
             T, BD = s.Beff * s.n_tok, s.Beff * s.D  # noqa: N806
-            pe = m.patch_embed[s.embed].patchify_bands[0]
+            pe = m.patch_embed[s.embed].patchify_bands[s.gi]
             self.mb[name] = dict(cols=e(T, s.Kpad, dt=BF16), yconv=e(T, E), gn_partial=e(hip.groupnorm_partial_size(BD, s.L, E)),
                                  gn_stats=e(BD, 2), gn_sums=e(BD, 2), pos_enc=m.pos_enc_rows[name].to(dev),
                                  norm_bands=torch.tensor(s.norm_bands, dtype=I32, device=dev),
@@ -138,10 +138,11 @@ class SupervisedEngine(EngineBase):
         if self.store.refresh_half():
             self._pack_conv_weights()
         batch = dict(batch)
-        for s in self.mods.values():
-            img = batch[s.name]
+        sources = [parts[0] for parts in self.model.src_specs.values()]      # one spec per batch entry (band-group 0)
+        for s in sources:
+            img = batch[s.src]
             if img.dtype != F32 or not img.is_contiguous() or not img.is_cuda:
-                raise ValueError(f"batch[{s.name!r}] must be a contiguous float32 GPU tensor")
+                raise ValueError(f"batch[{s.src!r}] must be a contiguous float32 GPU tensor")
         for t, c in self.model.dataset.targets.items():
             y = batch[t]
             if not y.is_cuda or not y.is_contiguous():
@@ -151,17 +152,17 @@ class SupervisedEngine(EngineBase):
             elif c.type_target != "multilabel_classif" and y.dtype.is_floating_point:
                 batch[t] = y.long()
         batch = self._stable_inputs(batch)
-        for s in self.mods.values():
-            img = batch[s.name]
+        for s in sources:
+            img = batch[s.src]
             if tuple(img.shape[-2:]) != (s.S, s.S) or self.model.interpolate != "nearest":
                 mode = {"nearest": 0, "bilinear": 1, "bicubic": 2}.get(self.model.interpolate)
                 if mode is None:
                     raise ValueError(f"Invalid interpolate mode {self.model.interpolate!r} (nearest, bilinear, bicubic)")
                 buf = self.mb[s.name].get("resized")
                 if buf is None:
-                    buf = self.mb[s.name]["resized"] = torch.empty(self.B, s.Dates, s.C, s.S, s.S, dtype=F32, device=self.device)
-                hip.resize(img, buf, self.B * s.Dates * s.C, img.shape[-2], img.shape[-1], s.S, s.S, mode)
-                batch[s.name] = buf
+                    buf = self.mb[s.name]["resized"] = torch.empty(self.B, s.Dates, s.C_src, s.S, s.S, dtype=F32, device=self.device)
+                hip.resize(img, buf, self.B * s.Dates * s.C_src, img.shape[-2], img.shape[-1], s.S, s.S, mode)
+                batch[s.src] = buf
         self._staged = batch
         key = self._cur_key = tuple(batch[k].data_ptr() for k in sorted(batch) if isinstance(batch[k], torch.Tensor))
         with self._tuning_pass("forward"):
@@ -176,13 +177,13 @@ class SupervisedEngine(EngineBase):
         for s in g.mods:
             b = self.mb[s.name]
             BD = s.Beff * s.D  # noqa: N806
-            hip.patchify(batch[s.name], b["cols"], None, BD, s.C, s.S, s.P, s.Kpad, b["norm_bands"], len(s.norm_bands), False,
-                         s.rescale_elev)
+            hip.patchify_bands(batch[s.src], b["cols"], None, BD, s.C_src, s.c0, s.C, s.S, s.P, s.Kpad, None, 0, False,
+                               s.rescale_elev)            # (band-group window of the raster; the whole raster when there is one)
             if s.D != s.Dates:   # dates folded into the batch: one date row per sequence
-                hip.date_features(batch[f"{s.name}_dates"], batch["ref_date"], gbuf["dates"].view(B, s.Dates, 8), B, s.Dates,
+                hip.date_features(batch[f"{s.src}_dates"], batch["ref_date"], gbuf["dates"].view(B, s.Dates, 8), B, s.Dates,
                                   s.Dates, 0, m.fac_date_enc)
             else:
-                hip.date_features(batch[f"{s.name}_dates"], batch["ref_date"], gbuf["dates"], B, s.D, gbuf["n_dates"], s.date_off,
+                hip.date_features(batch[f"{s.src}_dates"], batch["ref_date"], gbuf["dates"], B, s.D, gbuf["n_dates"], s.date_off,
                                   m.fac_date_enc)
             pe = b["pe"]
             T = s.Beff * s.n_tok  # noqa: N806
@@ -471,11 +472,12 @@ class SupervisedEngine(EngineBase):
     def returned_batch(self, batch: dict) -> dict:
         """The reference returns the resized / elevation-rescaled batch (mim.py:425-437)."""
         out = dict(batch)
-        out.update({s.name: self._staged[s.name] for s in self.mods.values()})
-        for s in self.mods.values():
+        sources = [parts[0] for parts in self.model.src_specs.values()]
+        out.update({s.src: self._staged[s.src] for s in sources})
+        for s in sources:
             if s.rescale_elev:
-                img = out[s.name]
+                img = out[s.src]
                 res = torch.empty_like(img)
-                hip.rescale_elev(img, res, img.shape[0] * img.shape[1], s.C, s.S)
-                out[s.name] = res
+                hip.rescale_elev(img, res, img.shape[0] * img.shape[1], s.C_src, s.S)
+                out[s.src] = res
         return out

@@ -242,6 +242,13 @@ def patchify(img, cols, target, BD, Ctot, S, P, Kpad, norm_bands, n_groups, norm
          _I(int(normalise)), _I(int(rescale_elev)))
 
 
+def patchify_bands(img, cols, target, BD, Csrc, c0, Ctot, S, P, Kpad, norm_bands, n_groups, normalise, rescale_elev):
+    """``patchify`` of channels ``c0 .. c0 + Ctot - 1`` of an image with ``Csrc`` channels (one band-group); ``cols`` or
+    ``target`` may be None."""
+    call("mh_patchify_bands", img, cols, target, _I(BD), _I(Csrc), _I(c0), _I(Ctot), _I(S), _I(P), _I(Kpad), norm_bands,
+         _I(n_groups), _I(int(normalise)), _I(int(rescale_elev)))
+
+
 def groupnorm_partial_size(BD, L, E) -> int:
     return int(lib().mh_groupnorm_partial_size(_I(BD), _I(L), _I(E)))
 
@@ -303,6 +310,15 @@ def unmask_token_grad(dxdec, mask, tok_slot, dmask_token, B, L, Dd, slot, t_lo, 
 
 def count_masked(mask, B, L, t_lo, t_hi, out):
     call("mh_count_masked", mask, _I(B), _I(L), _I(t_lo), _I(t_hi), out)
+
+
+def count_masked_elems(mask, B, L, t_lo, t_hi, out, mult, accumulate):
+    call("mh_count_masked_elems", mask, _I(B), _I(L), _I(t_lo), _I(t_hi), out, _I(mult), _I(int(accumulate)))
+
+
+def masked_loss_bands(rec, target, mask_group, n_elems, weight, acc, drec, B, Lm, Lgroup, tok_off, PPC, p, tgt_C, tgt_c0, n_g):  # noqa: N803
+    call("mh_masked_loss_bands", rec, target, mask_group, n_elems, _F(weight), acc, drec, _I(B), _I(Lm), _I(Lgroup),
+         _I(tok_off), _I(PPC), _I(p), _I(tgt_C), _I(tgt_c0), _I(n_g))
 
 
 def masked_loss(rec, target, mask_group, n_masked, weight, acc, drec, B, Lm, Lgroup, tok_off, PPC, p):

@@ -49,17 +49,20 @@ def draw_struct_masks(groups, mods, generator=None) -> dict[str, Tensor]:
     while any(bool(p.any()) for p in pending.values()):
         draw = {}
         for m in mods.values():
-            B, D, L = m.Beff, m.D, m.L  # noqa: N806  (len_bands == 1)
-            mk = torch.zeros(B, 1, D, L, dtype=torch.bool)
+            if m.gi:                     # band-groups 1.. of a modality: drawn together with its group 0
+                continue
+            B, D, L, G = m.Beff, m.D, m.L, m.G  # noqa: N806
+            mk = torch.zeros(B, G, D, L, dtype=torch.bool)
             if m.p_mod:
                 mk = mk | (torch.rand((B, 1, 1, 1), generator=generator) < m.p_mod)
             if m.p_bands:
-                mk = mk | (torch.rand((B, 1, 1, 1), generator=generator) < m.p_bands)
+                mk = mk | (torch.rand((B, G, 1, 1), generator=generator) < m.p_bands)
             if m.p_dates:
                 mk = mk | (torch.rand((B, 1, D, 1), generator=generator) < m.p_dates)
             if m.p_loc:
                 mk = mk | (torch.rand((B, 1, 1, L), generator=generator) < m.p_loc)
-            draw[m.name] = mk.reshape(B, D * L)
+            for gi in range(G):          # the specs of one modality are named <modality>#<g> when there are several
+                draw[m.name if G == 1 else f"{m.src}#{gi}"] = mk[:, gi].reshape(B, D * L)
         for g in groups:
             new = torch.cat([draw[m.name] for m in g.mods], dim=1)
             take = pending[g.name]

@@ -27,12 +27,15 @@ from maestro_amd.layers.vit import Transformer
 
 @dataclass
 class ModSpec:
-    """Geometry of one input modality as the engine sees it."""
+    """Geometry of one input modality as the engine sees it -- or of ONE BAND-GROUP of a modality with several
+    (``bands=[[..], [..]]``): ``Patchify`` gives every band-group its own conv + GroupNorm and stacks the groups on the date
+    axis (``maestro/layers/embed.py:18-34``, order (g, d)), so for everything between patch embedding and pixelify a band-group
+    IS a modality with ``D`` date slots of its own; ``src`` names the batch entry, ``c0 .. c0 + C - 1`` its channels there."""
 
-    name: str
+    name: str             # modality name, or "<modality>#<g>" for band-group g of a modality with several
     embed: str            # key in patch_embed / embed_to_rec (name_embed sharing, mim.py:62-69)
     group: str
-    C: int                # bands
+    C: int                # bands (of this band-group)
     S: int                # image size
     P: int                # patch size
     g: int                # grid
@@ -49,6 +52,11 @@ class ModSpec:
     p_bands: float | None = None
     p_dates: float | None = None
     p_loc: float | None = None
+    src: str = ""         # batch key of the rasters / dates (== name unless the modality has several band-groups)
+    gi: int = 0           # band-group index: patchify_bands[gi], pixelify_bands[gi], mask_token[0, gi]
+    c0: int = 0           # first channel of the band-group in the source raster
+    C_src: int = 0        # channels of the source raster
+    G: int = 1            # band-groups of the source modality
 
     @property
     def K(self) -> int:  # noqa: N802
@@ -181,25 +189,31 @@ class MAE(nn.Module):
         self.mod_specs: dict[str, ModSpec] = {}
         self.group_specs: dict[str, GroupSpec] = {}
         for m, c in ds.inputs.items():
-            if self.len_bands[m] != 1:
+            G = self.len_bands[m]  # noqa: N806
+            if G != 1 and fold:
                 raise NotImplementedError(
-                    f"modality {m}: several band-groups (len_bands={self.len_bands[m]}) are not supported by the HIP "
-                    "engine yet (unused by every shipped dataset config, SURVEY Q18)")
+                    f"modality {m}: several band-groups (len_bands={G}) with fusion_mode={self.fusion_mode!r} (dates AND band-"
+                    "groups folded into the batch) are not supported by the HIP engine; 'mod' and 'group' fusion are "
+                    "(unused by every shipped dataset config, SURVEY Q18)")
             gname = group_of[m]
             g = self.grid_size[m]
             nb = tuple(c.norm_bands) if c.norm_bands is not None else tuple(self.num_bands[m])
-            spec = ModSpec(name=m, embed=self.mod_embed[m], group=gname, C=sum(self.num_bands[m]), S=c.image_size,
-                           P=c.patch_size.mae, g=g, L=g * g, D=1 if fold else c.num_dates, Dates=c.num_dates,
-                           norm_bands=nb, rescale_elev=bool(c.rescale_elev), p_mod=self.mask_mod[m],
-                           p_bands=self.mask_bands[m], p_dates=self.mask_dates[m], p_loc=self.mask_loc[m])
+            c_src, c0 = sum(self.num_bands[m]), 0
             if gname not in self.group_specs:
                 model_key = gname if gname in self.encoder else "shared"
                 self.group_specs[gname] = GroupSpec(name=gname, model=model_key, ratio=self.mask_ratio[gname])
             grp = self.group_specs[gname]
-            spec.tok_off, spec.date_off, spec.slot = grp.L, sum(x.D for x in grp.mods), len(grp.mods)
-            grp.mods.append(spec)
-            grp.L += spec.n_tok
-            self.mod_specs[m] = spec
+            for gi, n_g in enumerate(self.num_bands[m]):       # one spec per band-group, in (g, d) order on the date axis
+                spec = ModSpec(name=m if G == 1 else f"{m}#{gi}", embed=self.mod_embed[m], group=gname, C=n_g, S=c.image_size,
+                               P=c.patch_size.mae, g=g, L=g * g, D=1 if fold else c.num_dates, Dates=c.num_dates,
+                               norm_bands=nb, rescale_elev=bool(c.rescale_elev), p_mod=self.mask_mod[m],
+                               p_bands=self.mask_bands[m], p_dates=self.mask_dates[m], p_loc=self.mask_loc[m],
+                               src=m, gi=gi, c0=c0, C_src=c_src, G=G)
+                c0 += n_g
+                spec.tok_off, spec.date_off, spec.slot = grp.L, sum(x.D for x in grp.mods), len(grp.mods)
+                grp.mods.append(spec)
+                grp.L += spec.n_tok
+                self.mod_specs[spec.name] = spec
         off = 0
         for grp in self.group_specs.values():
             grp.k = round(grp.ratio * grp.L)  # Python banker's rounding, as the reference
@@ -209,6 +223,10 @@ class MAE(nn.Module):
         # constant positional rows per modality (enc: [L, E]; dec: [L, Dd]); built once
         self.pos_enc_rows = {m: pool_pos_table(self.enc_pos_encoding.cpu(), s.g) for m, s in self.mod_specs.items()}
         self.pos_dec_rows = {m: pool_pos_table(self.dec_pos_encoding.cpu(), s.g) for m, s in self.mod_specs.items()}
+        # source modalities (batch entries) -> their band-group specs
+        self.src_specs: dict[str, list] = {}
+        for s in self.mod_specs.values():
+            self.src_specs.setdefault(s.src, []).append(s)
 
     # ------------------------------------------------------------------------------------------ engine plumbing
     def engine(self, batch_size: int, device=None, loss: str = "l2_norm", dtype: str | None = None):

@@ -299,7 +299,7 @@ class SSLModule(_Base):
         sample; here only that sample is depatchified and blended.  Targets come from the RETURNED batch (resized,
         elevation-rescaled: ``model.py:255-266``), not from the caller's."""
         log_inputs, log_preds, log_targets = {}, {}, {}
-        for name_mod in self.model.mod_specs:
+        for name_mod in self.model.src_specs:
             if name_mod not in self.dataset.log_inputs:
                 continue
             tgt, rec, msk = engine.logged_sample(name_mod)

@@ -180,6 +180,19 @@ def case_table():
             mods=dict(aerial=dict(image_size=64, patch=16, bands=4, norm_bands=[1, 3], norm_fac=255.0),
                       spot=dict(image_size=32, patch=16, bands=3, norm_fac=255.0)),
             size="tiny", model_kw=dict(depth=3), inter_depth=1, fusion="group", B=2, seed=43, stress=True),   # (seed 41 has #struct-masked > k in one sample: tie-dependent)
+        # several band-groups per modality (embed.py:18-34, mim.py:49-57; no shipped config has them): every band-group has its
+        # own patch-embed / pixelify conv and mask token and sits on the date axis in (g, d) order; mask_bands draws per
+        # (sample, band-group); the norm_bands groups [1, 3] of the loss target STRADDLE the band-groups [2, 2]
+        "bg_aerial_s2": dict(
+            dataset="flair", ds_kwargs=dict(filter_inputs=["aerial", "s2"], filter_targets=[]),
+            mods=dict(aerial=dict(image_size=64, patch=16, bands=[[3, 0], [1, 2]], norm_bands=[1, 3], norm_fac=255.0)),
+            size="tiny", model_kw=dict(depth=3), inter_depth=1, fusion="group", B=2, seed=52, mask_kw=dict(mask_bands=0.3)),
+        # band-groups of different sizes ([1] and [1] of a 2-band elevation raster: rescale_elev refers to channel 0 of the
+        # RASTER, i.e. across the band-groups), one encoder per modality
+        "bg_dem_mod": dict(
+            dataset="flair", ds_kwargs=dict(filter_inputs=["dem", "s1_asc"], filter_targets=[], ref_input=None),
+            mods=dict(dem=dict(image_size=64, patch=32, bands=[[0], [1]], norm_fac=1000.0, rescale_elev=True)),
+            size="tiny", model_kw=dict(depth=2), inter_depth=1, fusion="mod", B=2, seed=61, mask_kw=dict(mask_bands=0.4)),
     }
 
 
@@ -205,6 +218,11 @@ def sup_case_table():
             dataset="pastis_hd", ds_kwargs=dict(filter_inputs=["s2", "s1_asc"], filter_targets=["pastis_seg", "pastis_mlc"]),
             mods=dict(), size="tiny", model_kw=dict(depth=2), inter_depth=1, fusion="group", type_head="attentive",
             B=2, seed=34),
+        # two band-groups of different sizes in the reference input of a segmentation target: the heads see G * D date slots
+        "sup_flair_bands": dict(
+            dataset="flair", ds_kwargs=dict(filter_inputs=["aerial", "s2"], filter_targets=["cosia"], crop_meters=51.2),
+            mods=dict(aerial=dict(image_size=64, patch=16, bands=[[3, 0, 1], [2]], norm_bands=[1, 3], norm_fac=255.0)),
+            size="tiny", model_kw=dict(depth=2), inter_depth=1, fusion="group", type_head="attentive", B=2, seed=37),
         # dates folded into the batch (utils.py:26-37): ONE encoder for every modality and date / one per modality;
         # the heads still see [B, sum(dates) * L] tokens (segmentation: every date's grid resized to the reference grid)
         "sup_flair_shared": dict(
@@ -236,6 +254,16 @@ def make_targets(dataset, B: int, seed: int) -> dict:  # noqa: N803
             y = torch.randint(0, c.num_classes, (B,), generator=g)
         out[t] = y
     return out
+
+
+def token_masks(pixel_mask: torch.Tensor, mod) -> torch.Tensor:
+    """Token-level view ``[B, G * D, L]`` of a pixel-level ``mask_rec`` ``[B, D, C, S, S]`` (the pixel mask is the token mask
+    repeated over the patch and over the channels of a band-group): top-left pixel of every patch, first channel of every
+    band-group, band-groups stacked on the date axis in (g, d) order as ``Patchify`` does (embed.py:31-34)."""
+    P = mod.patch_size.mae  # noqa: N806
+    sizes = [mod.bands] if isinstance(mod.bands, int) else [len(b) for b in mod.bands]
+    firsts = [sum(sizes[:i]) for i in range(len(sizes))]
+    return torch.cat([pixel_mask[:, :, c, ::P, ::P].flatten(2) for c in firsts], dim=1)
 
 
 def build_datasets(case: dict, ns) -> object:
@@ -337,7 +365,7 @@ def run_case(name: str, case: dict, ref, ours) -> dict:
                 treesatai_ts=ref.ts.TreeSatAITSConfig, pastis_hd=ref.pastis.PASTISHDConfig,
                 flair=ref.flair.FLAIRConfig, s2_naip=ref.s2.S2NAIPConfig).items()})))
     ds_our = build_datasets(case, ours)
-    mask_ref, mask_our = ref.MaskConfig(), ours.MaskConfig()
+    mask_ref, mask_our = ref.MaskConfig(**case.get("mask_kw", {})), ours.MaskConfig(**case.get("mask_kw", {}))
 
     torch.manual_seed(1000 + case["seed"])
     ssl = ref.model.SSLModule(datasets=ds_ref, mask=mask_ref, interpolate="nearest", fusion_mode=case["fusion"],
@@ -405,8 +433,7 @@ def run_case(name: str, case: dict, ref, ours) -> dict:
     for m in rec:
         out[f"pixels_rec/{m}"] = rec[m].detach().numpy().astype(np.float32)
         # reference's token-level mask (pixel mask is its repeat): take the top-left pixel of each patch, channel 0
-        P = ds_our.dataset.inputs[m].patch_size.mae  # noqa: N806
-        out[f"mask_tok/{m}"] = np.packbits(msk[m][:, :, 0, ::P, ::P].flatten(2).numpy(), axis=2)
+        out[f"mask_tok/{m}"] = np.packbits(token_masks(msk[m], ds_our.dataset.inputs[m]).numpy(), axis=2)
         out[f"target/{m}"] = rb[m].detach().numpy().astype(np.float32) if ds_our.dataset.inputs[m].rescale_elev \
             else np.zeros(0, np.float32)
 

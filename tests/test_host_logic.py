@@ -130,6 +130,41 @@ def test_struct_mask_draw_order_matches_oracle(fusion_mode):
         assert g.k == om.OracleMAE.num_masked(o.mask_ratio[g.name], g.L)
 
 
+@pytest.mark.parametrize("name", ["bg_aerial_s2", "bg_dem_mod"])
+def test_band_groups_specs_and_draws(name):
+    """Several band-groups per modality (``maestro/ssl/mim.py:49-57``, ``mae.py:193-210``): one spec per band-group in (g, d)
+    order on the group's token axis, and the host draws -- including the per-(sample, band-group) ``mask_bands`` draw --
+    equal the oracle's (which equal the reference's recorded draws, see ``tests/test_oracle_golden.py``)."""
+    from oracle.gen_golden import build_datasets, case_table
+    case = case_table()[name]
+    ds = build_datasets(case, conf)
+    mask = conf.MaskConfig(**case["mask_kw"])
+    kw = dict(fusion_mode=case["fusion"], inter_depth=case["inter_depth"], **ARGS, **case["model_kw"])
+    m = mae_tiny(datasets=ds, mask=mask, **kw)
+    o = om.build_oracle(ds, mask, model_size="tiny", **kw)
+    src = next(n for n, parts in m.src_specs.items() if len(parts) > 1)
+    parts = m.src_specs[src]
+    assert [p.name for p in parts] == [f"{src}#{i}" for i in range(len(parts))] and all(p.src == src for p in parts)
+    assert [p.c0 for p in parts] == [0] + list(torch.tensor([p.C for p in parts]).cumsum(0)[:-1])
+    assert all(b.tok_off == a.tok_off + a.n_tok and b.slot == a.slot + 1 for a, b in zip(parts, parts[1:]))
+    assert m.mask_token[src].shape[1] == len(parts) and parts[0].p_bands == case["mask_kw"]["mask_bands"]
+    B = 4  # noqa: N806
+    for s in m.mod_specs.values():
+        s.Beff = B
+    groups = list(m.group_specs.values())
+    for g in groups:
+        g.Beff = B
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        got = draw_struct_masks(groups, m.mod_specs)
+        torch.manual_seed(seed)
+        want = o.draw_struct_masks({g.name: (g.Beff, g.L) for g in groups})
+        for g in groups:
+            assert torch.equal(got[g.name], want[g.name][:, :, 0])
+    with pytest.raises(NotImplementedError, match="band-groups"):
+        mae_tiny(datasets=ds, mask=mask, **dict(kw, fusion_mode="shared", inter_depth=0))
+
+
 def test_onecycle_matches_torch_and_lr_rule():
     p = torch.nn.Parameter(torch.zeros(1))
     opt = torch.optim.AdamW([p], lr=1.0)

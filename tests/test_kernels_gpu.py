@@ -317,6 +317,69 @@ def test_masked_loss(dev, p, B, Lm, Lg, off, PPC):
     assert (drec.float() - rec.grad).abs().max() < 1e-2 * scale
 
 
+@pytest.mark.parametrize("elev", [False, True])
+@pytest.mark.parametrize("sizes", [(2, 2), (3, 1), (1, 1, 2)])
+def test_patchify_and_loss_over_band_groups(dev, sizes, elev):
+    """Several band-groups per modality (``mh_patchify_bands`` / ``mh_count_masked_elems`` / ``mh_masked_loss_bands``):
+    every band-group's im2col rows are the window of the plain kernel's rows, the elevation rescale refers to channel 0 of the
+    RASTER, and the modality's loss is ONE mean over the masked elements of all its band-groups, each group's reconstruction
+    compared with its (strided) window of the modality-level target."""
+    from maestro_amd import hip
+    from oracle import layers as ol
+    BD, S, P, C = 3, 32, 8, sum(sizes)  # noqa: N806
+    g, PP = S // P, P * P  # noqa: N806
+    T = BD * g * g  # noqa: N806
+    img = torch.rand(BD, C, S, S, generator=torch.Generator().manual_seed(11))
+    ref_img = img.clone()
+    if elev:
+        ref_img[:, 1:] = 30 * (ref_img[:, :1] - ref_img[:, 1:])
+    nb = torch.tensor([1, C - 1], dtype=torch.int32, device=dev)          # norm groups straddling the band-groups
+    K = C * PP  # noqa: N806
+    target = torch.zeros(T, K, device=dev)
+    want_t = torch.zeros(T, K, device=dev)
+    cols_full = torch.zeros(T, (K + 31) // 32 * 32, device=dev, dtype=torch.bfloat16)
+    hip.patchify_bands(img.to(dev), None, target, BD, C, 0, C, S, P, (K + 7) // 8 * 8, nb, 2, True, elev)
+    hip.patchify(img.to(dev), cols_full, want_t, BD, C, S, P, cols_full.shape[1], nb, 2, True, elev)
+    assert torch.equal(target, want_t)                                       # target-only mode = the plain kernel's target
+    Lg, off = g * g * len(sizes) + 5, 3  # noqa: N806
+    mask = (torch.rand(BD, Lg, generator=torch.Generator().manual_seed(5)) < 0.6).to(torch.uint8).to(dev)
+    cnt, acc, weight = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, device=dev), 0.41
+    recs, drecs, c0, tot, n_el = [], [], 0, 0.0, 0
+    for gi, n_g in enumerate(sizes):
+        Kg = n_g * PP  # noqa: N806
+        cols = torch.full((T, (Kg + 31) // 32 * 32), 3.0, device=dev, dtype=torch.bfloat16)
+        hip.patchify_bands(img.to(dev), cols, None, BD, C, c0, n_g, S, P, cols.shape[1], None, 0, False, elev)
+        want_cols = ol.im2col_patches(ref_img[:, c0: c0 + n_g], P).reshape(-1, Kg)
+        assert torch.equal(cols[:, :Kg].cpu(), want_cols.bfloat16()) and (cols[:, Kg:] == 0).all()
+        t_lo = off + gi * g * g
+        hip.count_masked_elems(mask, BD, Lg, t_lo, t_lo + g * g, cnt, Kg, gi > 0)
+        recs.append(_rand(T, Kg, seed=20 + gi).to(dev))
+        drecs.append(torch.full((T, Kg), 9.0, device=dev, dtype=torch.bfloat16))
+        c0 += n_g
+    # every sample's band-group tokens sit at [off + gi * L, off + (gi + 1) * L) of its row of the group mask: the loss kernel
+    # addresses them as "modality" rows b * L + t with tok_off = that start
+    c0 = 0
+    for gi, n_g in enumerate(sizes):
+        Kg, t_lo = n_g * PP, off + gi * g * g  # noqa: N806
+        hip.masked_loss_bands(recs[gi], target, mask, cnt, weight, acc, drecs[gi], BD, g * g, Lg, t_lo, Kg, 2, C, c0, n_g)
+        m = mask[:, t_lo: t_lo + g * g].reshape(-1).bool().cpu()
+        tw = target.view(T, PP, C)[:, :, c0: c0 + n_g].reshape(T, Kg).cpu()
+        tot += float(((recs[gi].cpu() - tw) ** 2)[m].double().sum())
+        n_el += int(m.sum()) * Kg
+        c0 += n_g
+    torch.cuda.synchronize()
+    assert int(cnt) == n_el
+    assert abs(acc.item() - weight * tot / n_el) < 1e-5 * max(1.0, weight * tot / n_el)
+    c0 = 0
+    for gi, n_g in enumerate(sizes):
+        Kg, t_lo = n_g * PP, off + gi * g * g  # noqa: N806
+        m = mask[:, t_lo: t_lo + g * g].reshape(-1).bool().cpu()
+        tw = target.view(T, PP, C)[:, :, c0: c0 + n_g].reshape(T, Kg).cpu()
+        want = 2 * (recs[gi].cpu() - tw) * weight / n_el * m[:, None]
+        assert (drecs[gi].float().cpu() - want).abs().max() < 1e-2 * want.abs().max()
+        c0 += n_g
+
+
 # ----------------------------------------------------------------------------------------------- misc
 def test_colsum_cast_pack_adamw(dev):
     from maestro_amd import hip

@@ -17,7 +17,7 @@ import torch
 import maestro_amd.conf as conf
 from maestro_amd.ssl import mae as pmae
 from oracle import mae as om
-from oracle.gen_golden import build_datasets, case_table, init_weights, make_batch
+from oracle.gen_golden import build_datasets, case_table, init_weights, make_batch, token_masks
 
 pytestmark = pytest.mark.gpu
 CASES = case_table()
@@ -37,9 +37,10 @@ def _setup(name, golden_dir):
     gold = np.load(golden_dir / f"{name}.npz", allow_pickle=False)
     ds = build_datasets(case, conf)
     kw = dict(fusion_mode=case["fusion"], inter_depth=case["inter_depth"], **COMMON, **case["model_kw"])
-    oracle = om.build_oracle(ds, conf.MaskConfig(), model_size=case["size"], **kw)
+    mask_cfg = conf.MaskConfig(**case.get("mask_kw", {}))
+    oracle = om.build_oracle(ds, mask_cfg, model_size=case["size"], **kw)
     init_weights(oracle, case["seed"])
-    model = getattr(pmae, f"mae_{case['size']}")(datasets=ds, mask=conf.MaskConfig(), **kw)
+    model = getattr(pmae, f"mae_{case['size']}")(datasets=ds, mask=mask_cfg, **kw)
     missing, unexpected = model.load_state_dict(oracle.state_dict(), strict=True)
     batch = make_batch(ds.dataset, case["B"], case["seed"], stress=case.get("stress", False))
     noise, struct = {}, {}
@@ -73,10 +74,11 @@ def test_engine_matches_oracle_and_reference(golden_dir, name, wgrad, observed):
 
     group_of = dict(ds.dataset.groups) if case["fusion"] == "group" else {m: m for m in ds.dataset.inputs}
     multi = {g for g in set(group_of.values()) if sum(1 for v in group_of.values() if v == g) > 1}
+    # (several band-groups = several different mask tokens inside one modality: tie-dependent in the reference as well, Q5)
+    multi |= {group_of[m] for m, c in ds.dataset.inputs.items() if not isinstance(c.bands, int) and len(c.bands) > 1}
     for m in orec:
         assert torch.equal(masks[m].cpu(), omsk[m]), f"{m}: mask differs from oracle"
-        P = ds.dataset.inputs[m].patch_size.mae
-        tok = masks[m][:, :, 0, ::P, ::P].flatten(2).cpu().numpy()
+        tok = token_masks(masks[m].cpu(), ds.dataset.inputs[m]).numpy()
         ref_tok = np.unpackbits(gold[f"mask_tok/{m}"], axis=2)[:, :, : tok.shape[2]].astype(bool)
         assert np.array_equal(tok, ref_tok), f"{m}: mask indices differ from the reference"
         observed(f"tiny/{name}/{wgrad}", f"pixels/{m}", _rel(pixels[m].cpu(), orec[m].detach()))
