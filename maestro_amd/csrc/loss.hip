@@ -12,17 +12,20 @@ __global__ __launch_bounds__(256) void masked_loss_kernel(const float* __restric
                                                           const uint8_t* __restrict__ mask_group, const int* __restrict__ n_masked,
                                                           float weight, float* __restrict__ acc, bf16_t* __restrict__ drec,
                                                           int B, int Lm, int Lgroup, int tok_off, int PPC, int p, int tgt_C,
-                                                          int tgt_c0, int n_g, int denom_is_elems) {
+                                                          int tgt_c0, int n_g, int denom_is_elems, int rows_per_wave) {
     // band window (several band-groups per modality): rec column k = pixel * n_g + c pairs with target column
     // pixel * tgt_C + tgt_c0 + c of the MODALITY's target rows (tgt_C channels); n_g == tgt_C: the plain case
     __shared__ float red[4];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + w;
     const float coef = weight / (denom_is_elems ? (float)(*n_masked) : (float)(*n_masked) * (float)PPC);
     const bool window = n_g != tgt_C;
     const int tgt_ld = window ? PPC / n_g * tgt_C : PPC;
     float s = 0.f;
-    if (row < B * Lm) {
+    // several rows per wave: the block's ONE atomic into the loss word costs ~10 ns of serialised time (same-line atomics,
+    // scripts/micro_amax.hip) -- 8192 blocks of 4 rows made the aerial modality's launch 80 us of atomics
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
+        const int row = (blockIdx.x * 4 + w) * rows_per_wave + rr;
+        if (row >= B * Lm) break;
         const int b = row / Lm, t = row - b * Lm;
         const bool masked = mask_group[(size_t)b * Lgroup + tok_off + t] != 0;
         const float* r = rec + (size_t)row * PPC;
@@ -235,6 +238,9 @@ __global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, l
 
 }  // namespace
 
+// rows per wave of masked_loss_kernel: about 1024 workgroups (= same-word atomics) per launch, at most 16 rows per wave
+static int loss_rows_per_wave(long rows) { return (int)std::min(16L, std::max(1L, rows / 4096)); }
+
 extern "C" int mh_scale_dev(float* x, long n, const float* scale, void* stream) {
     MH_CHECK_ARG(x && scale && n > 0 && ((uintptr_t)x % 16) == 0, "mh_scale_dev: bad arguments (x 16-byte aligned)");
     hipLaunchKernelGGL(scale_dev_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, scale);
@@ -247,8 +253,9 @@ extern "C" int mh_masked_loss(const float* rec, const float* target, const uint8
                               void* stream) {
     MH_CHECK_ARG(rec && target && mask_group && n_masked && acc, "mh_masked_loss: null pointer");
     MH_CHECK_ARG((p == 1 || p == 2) && PPC % 4 == 0 && tok_off + Lm <= Lgroup, "mh_masked_loss: bad arguments");
-    hipLaunchKernelGGL(masked_loss_kernel, dim3(ceil_div((long)B * Lm, 4)), dim3(256), 0, (hipStream_t)stream, rec, target, mask_group, n_masked,
-                       weight, acc, (bf16_t*)drec, B, Lm, Lgroup, tok_off, PPC, p, 1, 0, 1, 0);
+    const int rpw = loss_rows_per_wave((long)B * Lm);
+    hipLaunchKernelGGL(masked_loss_kernel, dim3(ceil_div((long)B * Lm, 4 * rpw)), dim3(256), 0, (hipStream_t)stream, rec, target, mask_group, n_masked,
+                       weight, acc, (bf16_t*)drec, B, Lm, Lgroup, tok_off, PPC, p, 1, 0, 1, 0, rpw);
     MH_LAUNCH_CHECK();
     return 0;
 }
@@ -260,8 +267,9 @@ extern "C" int mh_masked_loss_bands(const float* rec, const float* target, const
     MH_CHECK_ARG((p == 1 || p == 2) && PPC % 4 == 0 && tok_off + Lm <= Lgroup, "mh_masked_loss_bands: bad arguments");
     MH_CHECK_ARG(n_g > 0 && PPC % n_g == 0 && tgt_c0 >= 0 && tgt_c0 + n_g <= tgt_C, "mh_masked_loss_bands: band window [%d, %d) of %d",
                  tgt_c0, tgt_c0 + n_g, tgt_C);
-    hipLaunchKernelGGL(masked_loss_kernel, dim3(ceil_div((long)B * Lm, 4)), dim3(256), 0, (hipStream_t)stream, rec, target, mask_group, n_elems,
-                       weight, acc, (bf16_t*)drec, B, Lm, Lgroup, tok_off, PPC, p, tgt_C, tgt_c0, n_g, 1);
+    const int rpw = loss_rows_per_wave((long)B * Lm);
+    hipLaunchKernelGGL(masked_loss_kernel, dim3(ceil_div((long)B * Lm, 4 * rpw)), dim3(256), 0, (hipStream_t)stream, rec, target, mask_group, n_elems,
+                       weight, acc, (bf16_t*)drec, B, Lm, Lgroup, tok_off, PPC, p, tgt_C, tgt_c0, n_g, 1, rpw);
     MH_LAUNCH_CHECK();
     return 0;
 }
