@@ -15,6 +15,35 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
+
+// Softmax VALU arithmetic on four scores at a time.  ATTN_SCALAR_VALU=1 (with -fno-slp-vectorize) keeps every operation a
+// scalar v_fma_f32 / v_add_f32 / v_mul_f32; 0 writes whole-vector expressions, which the compiler turns into packed
+// v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 (two floats per instruction).
+#ifndef ATTN_SCALAR_VALU
+#define ATTN_SCALAR_VALU 1
+#endif
+__device__ __forceinline__ f32x4 fms4(f32x4 a, float c, f32x4 b) {   // a * c - b
+#if ATTN_SCALAR_VALU
+    return (f32x4){__builtin_fmaf(a[0], c, -b[0]), __builtin_fmaf(a[1], c, -b[1]), __builtin_fmaf(a[2], c, -b[2]),
+                   __builtin_fmaf(a[3], c, -b[3])};
+#else
+    return a * (f32x4){c, c, c, c} - b;
+#endif
+}
+__device__ __forceinline__ f32x4 scale4(f32x4 a, float c) {
+#if ATTN_SCALAR_VALU
+    return (f32x4){a[0] * c, a[1] * c, a[2] * c, a[3] * c};
+#else
+    return a * c;
+#endif
+}
+__device__ __forceinline__ f32x4 mul_add4(f32x4 p, f32x4 a, f32x4 b) {   // p * (a + b)
+#if ATTN_SCALAR_VALU
+    return (f32x4){p[0] * (a[0] + b[0]), p[1] * (a[1] + b[1]), p[2] * (a[2] + b[2]), p[3] * (a[3] + b[3])};
+#else
+    return p * (a + b);
+#endif
+}
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
 template <int D> __device__ __forceinline__ int row_swz(int row) {
@@ -186,19 +215,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             const float mc = mx * c;
             // the softmax is VALU-bound (D = 32: ~4 VALU cycles per MFMA cycle): whole-vector expressions so that the
             // scale / shift and the row sum become packed v_pk_fma_f32 / v_pk_add_f32 (two floats per instruction)
-            const f32x4 c4 = {c, c, c, c}, mc4 = {mc, mc, mc, mc};
+            const f32x4 mc4 = {mc, mc, mc, mc};
+#if ATTN_SCALAR_VALU
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#else
             f32x4 ps4 = {0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const f32x4 t = s[qt][kt] * c4 - mc4;
+                const f32x4 t = fms4(s[qt][kt], c, mc4);
                 const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
                 s[qt][kt] = pv;
+#if ATTN_SCALAR_VALU
+                p0 += pv[0]; p1 += pv[1]; p2 += pv[2]; p3 += pv[3];
+#else
                 ps4 += pv;
+#endif
             }
+#if ATTN_SCALAR_VALU
+            const float ps = (p0 + p1) + (p2 + p3);
+#else
             const float ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+#endif
             lsum[qt] = lsum[qt] * alpha + ps;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+            for (int dt = 0; dt < DT; ++dt) o[qt][dt] = scale4(o[qt][dt], alpha);
             pf[qt][0] = pack_acc(s[qt][0], s[qt][1]);
             pf[qt][1] = pack_acc(s[qt][2], s[qt][3]);
         }
@@ -337,13 +378,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         bf16x8 dsf[2][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            const f32x4 c4 = {c, c, c, c}, l4 = {lse2[qt], lse2[qt], lse2[qt], lse2[qt]};
+            const f32x4 l4 = {lse2[qt], lse2[qt], lse2[qt], lse2[qt]};
             const f32x4 nd4 = {-dlt[qt], -dlt[qt], -dlt[qt], -dlt[qt]};
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const f32x4 t = s[qt][kt] * c4 - l4;
+                const f32x4 t = fms4(s[qt][kt], c, l4);
                 const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
-                s[qt][kt] = pv * (dp[qt][kt] + nd4);  // dS / scale; the factor is applied to dQ once at the end
+                s[qt][kt] = mul_add4(pv, dp[qt][kt], nd4);  // dS / scale; the factor is applied to dQ once at the end
             }
             dsf[qt][0] = pack_acc(s[qt][0], s[qt][1]);
             dsf[qt][1] = pack_acc(s[qt][2], s[qt][3]);
@@ -463,13 +504,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         for (int qt = 0; qt < 4; ++qt) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
             const f32x4 nd4 = *reinterpret_cast<const f32x4*>(s_dlt + 16 * qt + 4 * g);
-            const f32x4 c4 = {c, c, c, c};
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                const f32x4 t = s[qt][kt] * c4 - l4;                   // query >= N: lse2 = +inf -> probability 0
+                const f32x4 t = fms4(s[qt][kt], c, l4);                // query >= N: lse2 = +inf -> probability 0
                 const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
                 s[qt][kt] = pv;
-                dp[qt][kt] = pv * (dp[qt][kt] + nd4);                  // dS / scale (applied to dK at the end)
+                dp[qt][kt] = mul_add4(pv, dp[qt][kt], nd4);            // dS / scale (applied to dK at the end)
             }
         }
 #pragma unroll

@@ -23,7 +23,10 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 # Per-file code-generation flags.  attn.hip: keep the MFMA accumulators in VGPRs -- the softmax reads every score on the
 # VALU, and with AGPR accumulators each tile paid 64-160 v_accvgpr_read/write moves (VALU-bound kernels: -25..-40 % cycles).
-FILE_FLAGS = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# -fno-slp-vectorize + scalar source (ATTN_SCALAR_VALU, default 1): packed v_pk_fma_f32 / v_pk_add_f32 beside MFMAs are no faster
+# than two scalar instructions on gfx950 and measured 0-6 % slower here (scripts/bench_attn.py: backward N = 576, D = 32:
+# 160 -> 150 us; N = 1024: 379 -> 370; forward +-1 %).  MH_ATTN_FLAGS="-DATTN_SCALAR_VALU=0" rebuilds the packed form.
+FILE_FLAGS = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"] + os.environ.get("MH_ATTN_FLAGS", "").split()}
 
 
 def _hipcc() -> str:
