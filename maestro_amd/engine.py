@@ -793,8 +793,22 @@ class MAEEngine(EngineBase):
     def draw_masks(self, generator=None):
         """Host draws in the reference's order: structural masks first, then ``rand(B, L)`` per group."""
         struct = draw_struct_masks(self.groups, self.mods, generator)
-        noise = {g.name: torch.rand((g.Beff, g.L), generator=generator) for g in self.groups}
+        noise = {}
+        for g in self.groups:       # one draw per REFERENCE group (a folded modality with several band-groups: one for all of them)
+            if g.draw not in noise:
+                noise[g.draw] = torch.rand((g.Beff * g.draw_G, g.L), generator=generator)
         return noise, struct
+
+    @staticmethod
+    def _rows_of(draws: dict, g) -> torch.Tensor:
+        """This group's rows of a per-reference-group host draw ``[Beff_ref, L]`` (see ``GroupSpec.draw``)."""
+        if g.name in draws:
+            return draws[g.name]
+        t = draws[g.draw]
+        if g.draw_G == 1:
+            return t
+        D = g.mods[0].Dates  # noqa: N806   sequence (b, band-group, date) of the folded modality -> row (b, date) of this group
+        return t.reshape(g.Beff // D, g.draw_G, D, -1)[:, g.draw_g].reshape(g.Beff, -1)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, batch: dict, noise: dict | None = None, struct: dict | None = None) -> torch.Tensor:
@@ -819,8 +833,8 @@ class MAEEngine(EngineBase):
         for g in self.groups:
             gbuf = self.gb[g.name]
             nh, sh = gbuf["noise_h"][slot], gbuf["struct_h"][slot]
-            nh.copy_(noise[g.name])
-            sh.copy_(struct[g.name].reshape(g.Beff, g.L))
+            nh.copy_(self._rows_of(noise, g))
+            sh.copy_(self._rows_of(struct, g).reshape(g.Beff, g.L))
             gbuf["noise"].copy_(nh, non_blocking=True)
             gbuf["struct"].copy_(sh, non_blocking=True)
         if self._opt is not None:      # overlapped optimizer: this step's scalars (or "nothing pending") ride the same ring
@@ -1057,9 +1071,7 @@ class MAEEngine(EngineBase):
                          s.K, hip.OUT_F32 | hip.BIAS, bias=conv.bias)
                 if s.G == 1:
                     hip.count_masked(gbuf["mask"], g.Beff, g.L, s.tok_off, s.tok_off + s.n_tok, b["cnt"])
-                else:       # masked ELEMENTS of the whole modality (its band-groups have different patch sizes in elements)
-                    hip.count_masked_elems(gbuf["mask"], g.Beff, g.L, s.tok_off, s.tok_off + s.n_tok, b["cnt"], s.K, s.gi > 0)
-            for s in g.mods:    # (after every band-group's count: the loss of a modality is ONE mean over its masked elements)
+            for s in g.mods:    # (several band-groups: counted by count_band_group_elems, before any decoder side starts)
                 b = self.mb[s.name]
                 if s.G == 1:
                     hip.masked_loss(b["rec"], b["target"], gbuf["mask"], b["cnt"], self.loss_w[s.src], self.loss_acc,
@@ -1076,6 +1088,15 @@ class MAEEngine(EngineBase):
             self._run_parallel([head(g) for g in self.groups])
         if self.joint is not None:
             (self.joint_set or self.joint).forward(lambda l: self._opt_wait("joint", l))
+        # a modality with several band-groups: masked ELEMENTS over all of them (their patches differ in size, and under
+        # 'shared' / 'monotemp' fusion they live in different sequence sets on different streams) -- the denominator of the
+        # modality's loss, needed by every band-group's loss launch: counted here, on the main stream, all masks being final
+        for parts in m.src_specs.values():
+            if len(parts) > 1:
+                for s in parts:
+                    g = m.group_specs[s.group]
+                    hip.count_masked_elems(self.gb[g.name]["mask"], g.Beff, g.L, s.tok_off, s.tok_off + s.n_tok,
+                                           self.mb[s.name]["cnt"], s.K, s.gi > 0)
         if self.dec_set is not None:
             self._run_parallel([tail(g, "pre") for g in self.groups])
             self.dec_set.forward(lambda l: self._opt_wait("dec", l))

@@ -81,6 +81,12 @@ class GroupSpec:
     ratio: float = 0.75
     Beff: int = 0
     joint_off: int = 0
+    # the REFERENCE group whose ``rand(Beff, L)`` draw feeds this one.  Differs from ``name`` only for a modality with several
+    # band-groups under 'shared' / 'monotemp' fusion: there band-groups AND dates are folded into the batch (sequence index
+    # (b, g, d), utils.py:26-37), every band-group runs as a sequence set of its own and takes rows (b, draw_g, d) of the draw
+    draw: str = ""
+    draw_g: int = 0
+    draw_G: int = 1
 
     @property
     def N(self) -> int:  # noqa: N802
@@ -190,21 +196,19 @@ class MAE(nn.Module):
         self.group_specs: dict[str, GroupSpec] = {}
         for m, c in ds.inputs.items():
             G = self.len_bands[m]  # noqa: N806
-            if G != 1 and fold:
-                raise NotImplementedError(
-                    f"modality {m}: several band-groups (len_bands={G}) with fusion_mode={self.fusion_mode!r} (dates AND band-"
-                    "groups folded into the batch) are not supported by the HIP engine; 'mod' and 'group' fusion are "
-                    "(unused by every shipped dataset config, SURVEY Q18)")
             gname = group_of[m]
             g = self.grid_size[m]
             nb = tuple(c.norm_bands) if c.norm_bands is not None else tuple(self.num_bands[m])
             c_src, c0 = sum(self.num_bands[m]), 0
-            if gname not in self.group_specs:
-                model_key = gname if gname in self.encoder else "shared"
-                self.group_specs[gname] = GroupSpec(name=gname, model=model_key, ratio=self.mask_ratio[gname])
-            grp = self.group_specs[gname]
+            model_key = gname if gname in self.encoder else "shared"
             for gi, n_g in enumerate(self.num_bands[m]):       # one spec per band-group, in (g, d) order on the date axis
-                spec = ModSpec(name=m if G == 1 else f"{m}#{gi}", embed=self.mod_embed[m], group=gname, C=n_g, S=c.image_size,
+                # (dates folded into the batch: the band-groups are folded with them -> one sequence set per band-group)
+                pname = f"{gname}#{gi}" if (fold and G > 1) else gname
+                if pname not in self.group_specs:
+                    self.group_specs[pname] = GroupSpec(name=pname, model=model_key, ratio=self.mask_ratio[gname], draw=gname,
+                                                        draw_g=gi, draw_G=G if fold else 1)
+                grp = self.group_specs[pname]
+                spec = ModSpec(name=m if G == 1 else f"{m}#{gi}", embed=self.mod_embed[m], group=pname, C=n_g, S=c.image_size,
                                P=c.patch_size.mae, g=g, L=g * g, D=1 if fold else c.num_dates, Dates=c.num_dates,
                                norm_bands=nb, rescale_elev=bool(c.rescale_elev), p_mod=self.mask_mod[m],
                                p_bands=self.mask_bands[m], p_dates=self.mask_dates[m], p_loc=self.mask_loc[m],

@@ -193,6 +193,11 @@ def case_table():
             dataset="flair", ds_kwargs=dict(filter_inputs=["dem", "s1_asc"], filter_targets=[], ref_input=None),
             mods=dict(dem=dict(image_size=64, patch=32, bands=[[0], [1]], norm_fac=1000.0, rescale_elev=True)),
             size="tiny", model_kw=dict(depth=2), inter_depth=1, fusion="mod", B=2, seed=61, mask_kw=dict(mask_bands=0.4)),
+        # band-groups AND dates folded into the batch (utils.py:26-37: sequence index (b, g, d)), one encoder per modality
+        "bg_ts_monotemp": dict(
+            dataset="treesatai_ts", ds_kwargs=dict(filter_targets=[]),
+            mods=dict(aerial=dict(image_size=60, patch=20, bands=[[0, 1, 2], [3]], norm_bands=[1, 3], norm_fac=255.0)),
+            size="tiny", model_kw=dict(depth=2), inter_depth=0, fusion="monotemp", B=2, seed=71),
     }
 
 
@@ -223,6 +228,10 @@ def sup_case_table():
             dataset="flair", ds_kwargs=dict(filter_inputs=["aerial", "s2"], filter_targets=["cosia"], crop_meters=51.2),
             mods=dict(aerial=dict(image_size=64, patch=16, bands=[[3, 0, 1], [2]], norm_bands=[1, 3], norm_fac=255.0)),
             size="tiny", model_kw=dict(depth=2), inter_depth=1, fusion="group", type_head="attentive", B=2, seed=37),
+        "sup_bands_shared": dict(
+            dataset="flair", ds_kwargs=dict(filter_inputs=["aerial", "s2"], filter_targets=["cosia"], crop_meters=51.2),
+            mods=dict(aerial=dict(image_size=64, patch=16, bands=[[3, 0], [1, 2]], norm_bands=[1, 3], norm_fac=255.0)),
+            size="tiny", model_kw=dict(depth=2), inter_depth=0, fusion="shared", type_head="attentive", B=2, seed=38),
         # dates folded into the batch (utils.py:26-37): ONE encoder for every modality and date / one per modality;
         # the heads still see [B, sum(dates) * L] tokens (segmentation: every date's grid resized to the reference grid)
         "sup_flair_shared": dict(

@@ -161,8 +161,12 @@ def test_band_groups_specs_and_draws(name):
         want = o.draw_struct_masks({g.name: (g.Beff, g.L) for g in groups})
         for g in groups:
             assert torch.equal(got[g.name], want[g.name][:, :, 0])
-    with pytest.raises(NotImplementedError, match="band-groups"):
-        mae_tiny(datasets=ds, mask=mask, **dict(kw, fusion_mode="shared", inter_depth=0))
+    # dates folded into the batch: the band-groups fold with them -> one sequence set per band-group, rows (b, g, d) of the
+    # reference group's noise draw
+    f = mae_tiny(datasets=ds, mask=mask, **dict(kw, fusion_mode="shared", inter_depth=0))
+    fparts = [f.group_specs[p.group] for p in f.src_specs[src]]
+    assert [g.name for g in fparts] == [f"{src}#{i}" for i in range(len(parts))]
+    assert all(g.draw == src and g.draw_G == len(parts) and g.draw_g == i and g.model == "shared" for i, g in enumerate(fparts))
 
 
 def test_onecycle_matches_torch_and_lr_rule():
