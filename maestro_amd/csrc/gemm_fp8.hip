@@ -19,16 +19,21 @@
 
 namespace {
 
-constexpr int BK8 = 128, S8 = 2;
+constexpr int BK8 = 128;
 
 // Tile geometry: WM x WN waves, each a (16 MT) x 64 accumulator block.
 //   <2,4,8> 256 x 256, 512 threads, 128 KiB ring, one workgroup per CU: the large decoder / joint problems
 //   <2,2,4> 128 x 128, 256 threads,  64 KiB ring, TWO workgroups per CU (one's epilogue overlaps the other's main loop): the
 //           per-group encoder problems of C5 (M = 512 .. 4608 token rows: 54 .. 216 tiles of 256 x 256 would leave most of the
 //           256 CUs idle).  At one byte per element this tile moves the same operand bytes per FLOP as the bf16 256 x 256 tile.
-template <int WM_, int WN_, int MT_>
+//   <2,2,4,4> the same 128 x 128 tile with a FOUR-stage ring (128 KiB, one workgroup per CU, three K steps in flight) for long-K
+//           launches with at most one tile per CU anyway: measured (scripts/bench_fp8_gemm.py, isolated) 4608 x 768 x 3072:
+//           24.2 -> 21.9 us, 4608 x 512 x 3072: 23.2 -> 20.9; but 3-4 % SLOWER below 128 tiles or at K = 768 (512 x 768 x 3072:
+//           18.8 -> 19.6 us -- those launches are bound by the exposed wait -> barrier -> fragment-read -> MFMA chain of a
+//           single wave per SIMD, 0.8 us per K step, not by the DMA round trip), hence the narrow dispatch rule below.
+template <int WM_, int WN_, int MT_, int S8_ = 2>
 struct Tile8 {
-    static constexpr int WM = WM_, WN = WN_, MT = MT_;
+    static constexpr int WM = WM_, WN = WN_, MT = MT_, S8 = S8_;
     static constexpr int BM = 16 * MT * WM, BN = 64 * WN, NW = WM * WN, NT = 64 * NW;
     static constexpr int A_BYTES = BM * BK8, B_BYTES = BN * BK8, STAGE_BYTES = A_BYTES + B_BYTES, LDS_BYTES = S8 * STAGE_BYTES;
     static constexpr int PA = A_BYTES / 1024 / NW, PB = B_BYTES / 1024 / NW;   // one-KiB DMA pieces per wave and K step
@@ -38,6 +43,7 @@ struct Tile8 {
 };
 typedef Tile8<2, 4, 8> T8_256;
 typedef Tile8<2, 2, 4> T8_128;
+typedef Tile8<2, 2, 4, 4> T8_128D;
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((address_space(3))) void lds_void8;
@@ -85,6 +91,7 @@ __device__ __forceinline__ void gemm_fp8_body(const GemmParams& p, unsigned char
         const int row = (w + NW * h) * 8 + (l >> 3), pos = l & 7;
         vb[h] = (n0 + row) * p.ldb + ((pos ^ (row & 7)) << 4);
     }
+    constexpr int S8 = T::S8, DEPTH = S8 - 1;     // K steps in flight
     auto issue = [&](int t) {
         unsigned char* slot = smem + (t % S8) * T::STAGE_BYTES;
 #pragma unroll
@@ -102,9 +109,19 @@ __device__ __forceinline__ void gemm_fp8_body(const GemmParams& p, unsigned char
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    issue(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < nk) issue(d);
     for (int t = 0; t < nk; ++t) {
-        wait_vm8<0>();                    // my pieces of step t (the only DMA in flight) have landed
+        // my pieces of step t have landed: at most the later steps' pieces (PA + PB per step and wave) may still be in flight
+        if constexpr (DEPTH == 1) {
+            wait_vm8<0>();
+        } else {
+            const int later = min(nk - 1 - t, DEPTH - 1);
+            if (later >= 2) wait_vm8<2 * (PA + PB)>();
+            else if (later == 1) wait_vm8<PA + PB>();
+            else wait_vm8<0>();
+        }
         __builtin_amdgcn_s_barrier();     // everybody's have; step t-1 has been read by everybody -> its slot can be refilled
         const unsigned char* ta = smem + (t % S8) * T::STAGE_BYTES;
         const unsigned char* tb = ta + T::A_BYTES;
@@ -114,7 +131,7 @@ __device__ __forceinline__ void gemm_fp8_body(const GemmParams& p, unsigned char
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[i] = read_frag8(ta, wm + 16 * i);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < nk) issue(t + 1);     // streams under this step's MFMAs (32 cycles each, two waves per SIMD)
+        if (t + DEPTH < nk) issue(t + DEPTH);     // streams under this and the next steps' MFMAs
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int half = 0; half < MT / 4; ++half) {     // four m-tiles at a time: A fragments are 8 registers each
@@ -136,7 +153,7 @@ __device__ __forceinline__ void gemm_fp8_body(const GemmParams& p, unsigned char
 }
 
 template <class T, bool A_E5M2>
-__global__ __launch_bounds__(T::NT, 2) void gemm_fp8_kernel(GemmParams p) {
+__global__ __launch_bounds__(T::NT, T::S8 > 2 ? 1 : 2) void gemm_fp8_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[T::LDS_BYTES];   // the ONLY LDS object
     gemm_fp8_body<T, A_E5M2>(p, smem);
 }
@@ -189,10 +206,12 @@ extern "C" int mh_gemm_fp8(int M, int N, int K, const void* A8, int lda, int a_f
     // (scripts/bench_fp8_gemm.py): 128^2 is as fast or faster on every shape of the C5 / C3 steps (e.g. 8192 x 768 x 3072:
     // 1403 vs 855 TFLOP/s; 32768 x 3072 x 512: 1090 vs 1061), 256^2 wins at 16384 x 4096 x 4096 (2140 vs 1796).
     // MH_FP8_TILE=128|256 forces one (experiments).
-    const long tiles256 = (long)ceil_div(M, 256) * ceil_div(N, 256);
-    const char* force = getenv("MH_FP8_TILE");
+    const long tiles256 = (long)ceil_div(M, 256) * ceil_div(N, 256), tiles128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    const char* force = getenv("MH_FP8_TILE");       // "256", "128" (two-stage ring), "128d" (four-stage ring)
     const bool big = force ? force[0] == '2' : (tiles256 >= 768 && K >= 2048);
+    const bool deep = force ? (force[0] == '1' && force[3] == 'd') : (tiles128 > 128 && tiles128 <= 256 && K >= 2048);   // (256 CUs: at most one tile per CU)
     if (big) launch_fp8<T8_256>(p, a_format, (hipStream_t)stream);
+    else if (deep) launch_fp8<T8_128D>(p, a_format, (hipStream_t)stream);
     else launch_fp8<T8_128>(p, a_format, (hipStream_t)stream);
     MH_LAUNCH_CHECK();
     return 0;
