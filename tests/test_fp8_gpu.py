@@ -45,14 +45,14 @@ def test_quantiser_matches_torch_float8(dev, fmt, dtype):
     assert float(sc.scale[0]) == 1.0 and float(sc.descale[1]) == 1.0 / float(sc.scale[1])
 
 
-@pytest.mark.parametrize("tile", ["128", "256"])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 384), (1000, 136, 256), (64, 768, 768)])
+@pytest.mark.parametrize("tile", ["128", "128d", "256"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 384), (1000, 136, 256), (64, 768, 768), (130, 264, 1152)])
 @pytest.mark.parametrize("a_fmt", [0, 1])
 def test_gemm_fp8_integer_exact(dev, M, N, K, a_fmt, tile, monkeypatch):
     """Small integers are exact in e4m3 / e5m2 and every partial sum is exact in fp32: any mistake in the operand lane map,
     the swizzles, the K order or the tiling changes bits."""
     from maestro_amd import hip
-    monkeypatch.setenv("MH_FP8_TILE", tile)      # both tile shapes (the library picks by problem size otherwise)
+    monkeypatch.setenv("MH_FP8_TILE", tile)      # every tile / ring form (the library picks by problem size otherwise)
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randint(-4, 5, (M, K), generator=g).float()
     b = torch.randint(-4, 5, (N, K), generator=g).float()
