@@ -46,6 +46,9 @@ int mh_version(void);
 #define MH_GEMM_AUX_DGELU 128 /* with MH_GEMM_GELU: aux_out receives GELU'(pre-activation) (bf16) instead of the pre-activation: the
                                * CDF / PDF are already at hand in the forward epilogue, so the backward only multiplies */
 #define MH_GEMM_MULAUX 256    /* bf16 output only: C *= aux_in[M, N] (bf16) -- the backward of GELU with the saved derivative */
+#define MH_GEMM_AUX_U8 1024   /* the saved GELU derivative (aux_out of MH_GEMM_AUX_DGELU, aux_in of MH_GEMM_MULAUX) is stored as one
+                               * BYTE per element, code = round((GELU' + 0.13) * 200): GELU' lies in [-0.129, 1.129], the step of
+                               * 0.005 is about what bf16 resolves near 1; halves the derivative's HBM bytes (ldaux in bytes) */
 #define MH_GEMM_C8_E5M2 512   /* mh_gemm_fp8 only: the fp8 copy c8 of the output is e5m2 (a gradient: the next dgrad's A operand) */
 int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                  int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,

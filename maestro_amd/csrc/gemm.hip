@@ -332,6 +332,8 @@ extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, cons
     MH_CHECK_ARG(!(flags & (MH_GEMM_DGELU | MH_GEMM_MULAUX)) || (aux_in && ldaux % 8 == 0), "mh_gemm_bf16: dgelu / mulaux need aux_in, ldaux %% 8 == 0");
     MH_CHECK_ARG(!(flags & MH_GEMM_AUX_DGELU) || ((flags & MH_GEMM_GELU) && aux_out), "mh_gemm_bf16: aux_dgelu needs the GELU epilogue and aux_out");
     MH_CHECK_ARG(!((flags & MH_GEMM_DGELU) && (flags & MH_GEMM_MULAUX)), "mh_gemm_bf16: dgelu and mulaux exclude each other");
+    MH_CHECK_ARG(!(flags & MH_GEMM_AUX_U8) || ((flags & (MH_GEMM_AUX_DGELU | MH_GEMM_MULAUX)) && !(flags & MH_GEMM_DGELU)),
+                 "mh_gemm_bf16: MH_GEMM_AUX_U8 applies to the saved GELU derivative only (AUX_DGELU / MULAUX)");
     MH_CHECK_ARG(!(flags & MH_GEMM_GELU) || !aux_out || ldaux % 8 == 0, "mh_gemm_bf16: ldaux %% 8");
     MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || (flags & MH_GEMM_OUT_F32), "mh_gemm_bf16: atomic needs f32 output");
     MH_CHECK_ARG(!(flags & MH_GEMM_COLSUM) || (colsum && !(flags & MH_GEMM_OUT_F32)), "mh_gemm_bf16: colsum needs a pointer and bf16 output");

@@ -58,6 +58,22 @@ int gemm_dma_dispatch(int tile, int layout, int M, int N, int K, const void* A, 
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                       int ldaux, float* colsum, void* stream);
 
+// MH_GEMM_AUX_U8: the saved GELU derivative as a byte code, value = code / 200 - 0.13 (range [-0.129, 1.129] -> 0.2 .. 251.8)
+__device__ __forceinline__ u32x2 pack_dgelu_u8x8(f32x4 lo, f32x4 hi) {
+    unsigned a = 0, b = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        a = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(lo[e], 200.f, 26.f), e, a);   // (v_cvt_pk_u8_f32 rounds to nearest)
+        b = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(hi[e], 200.f, 26.f), e, b);
+    }
+    return (u32x2){a, b};
+}
+__device__ __forceinline__ f32x4 unpack_dgelu_u8x4(unsigned w) {
+    // ((float)(w >> 8k & 0xff) is one v_cvt_f32_ubyte<k>)
+    return (f32x4){__builtin_fmaf((float)(w & 0xffu), 0.005f, -0.13f), __builtin_fmaf((float)((w >> 8) & 0xffu), 0.005f, -0.13f),
+                   __builtin_fmaf((float)((w >> 16) & 0xffu), 0.005f, -0.13f), __builtin_fmaf((float)(w >> 24), 0.005f, -0.13f)};
+}
+
 // Epilogues.  fp32 output (bias / residual): straight from the accumulators, 16 bytes per lane, four lanes per 64-byte row
 // segment (measured faster than an LDS transposition: 152 -> 125 us on the decoder fc2 GEMM).  bf16 output (bias / GELU /
 // GELU' / aux): each wave transposes its tile through a private LDS region (passes of 32 rows, 68-float row pitch:
@@ -119,7 +135,14 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                 for (int pass = 0; pass < SUB; ++pass) {
                     const int m = m_base + RP * pass_m + pass * 8 + (l >> 3);
                     aux_pre[pass] = (u32x4){0, 0, 0, 0};
-                    if (m < p.M && n < p.N) aux_pre[pass] = *reinterpret_cast<const u32x4*>(p.aux_in + (size_t)m * p.ldaux + n);
+                    if (m < p.M && n < p.N) {
+                        if (p.flags & MH_GEMM_AUX_U8) {
+                            const u32x2 b8 = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint8_t*>(p.aux_in) + (size_t)m * p.ldaux + n);
+                            aux_pre[pass] = (u32x4){b8[0], b8[1], 0, 0};
+                        } else {
+                            aux_pre[pass] = *reinterpret_cast<const u32x4*>(p.aux_in + (size_t)m * p.ldaux + n);
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -136,18 +159,28 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                         if (p.aux_out) {
                             f32x4 a_lo = lo, a_hi = hi;     // saved for the backward: the pre-activation, or GELU' = CDF + x PDF
                             if (p.flags & MH_GEMM_AUX_DGELU) { a_lo = lo * d_lo + c_lo; a_hi = hi * d_hi + c_hi; }
-                            u32x4 pk = {pack_bf2(a_lo[0], a_lo[1]), pack_bf2(a_lo[2], a_lo[3]), pack_bf2(a_hi[0], a_hi[1]),
-                                        pack_bf2(a_hi[2], a_hi[3])};
-                            *reinterpret_cast<u32x4*>(p.aux_out + (size_t)m * p.ldaux + n) = pk;
+                            if (p.flags & MH_GEMM_AUX_U8) {
+                                *reinterpret_cast<u32x2*>(reinterpret_cast<uint8_t*>(p.aux_out) + (size_t)m * p.ldaux + n) =
+                                    pack_dgelu_u8x8(a_lo, a_hi);
+                            } else {
+                                u32x4 pk = {pack_bf2(a_lo[0], a_lo[1]), pack_bf2(a_lo[2], a_lo[3]), pack_bf2(a_hi[0], a_hi[1]),
+                                            pack_bf2(a_hi[2], a_hi[3])};
+                                *reinterpret_cast<u32x4*>(p.aux_out + (size_t)m * p.ldaux + n) = pk;
+                            }
                         }
                         lo *= c_lo; hi *= c_hi;
                     }
                     if (p.flags & MH_GEMM_MULAUX) {
                         const u32x4 pk = aux_pre[pass];
-                        lo *= (f32x4){__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
-                                      __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
-                        hi *= (f32x4){__uint_as_float(pk[2] << 16), __uint_as_float(pk[2] & 0xffff0000u),
-                                      __uint_as_float(pk[3] << 16), __uint_as_float(pk[3] & 0xffff0000u)};
+                        if (p.flags & MH_GEMM_AUX_U8) {
+                            lo *= unpack_dgelu_u8x4(pk[0]);
+                            hi *= unpack_dgelu_u8x4(pk[1]);
+                        } else {
+                            lo *= (f32x4){__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
+                                          __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+                            hi *= (f32x4){__uint_as_float(pk[2] << 16), __uint_as_float(pk[2] & 0xffff0000u),
+                                          __uint_as_float(pk[3] << 16), __uint_as_float(pk[3] & 0xffff0000u)};
+                        }
                     }
                     if (p.flags & MH_GEMM_DGELU) {
                         const u32x4 pk = aux_pre[pass];

@@ -187,6 +187,8 @@ extern "C" int mh_gemm_fp8(int M, int N, int K, const void* A8, int lda, int a_f
     MH_CHECK_ARG(!(flags & (MH_GEMM_DGELU | MH_GEMM_MULAUX)) || (aux_in && ldaux % 8 == 0), "mh_gemm_fp8: aux_in / ldaux");
     MH_CHECK_ARG(!(flags & MH_GEMM_AUX_DGELU) || ((flags & MH_GEMM_GELU) && aux_out), "mh_gemm_fp8: aux_dgelu needs GELU + aux_out");
     MH_CHECK_ARG(!(flags & MH_GEMM_GELU) || !aux_out || ldaux % 8 == 0, "mh_gemm_fp8: ldaux %% 8");
+    MH_CHECK_ARG(!(flags & MH_GEMM_AUX_U8) || ((flags & (MH_GEMM_AUX_DGELU | MH_GEMM_MULAUX)) && !(flags & MH_GEMM_DGELU)),
+                 "mh_gemm_fp8: MH_GEMM_AUX_U8 applies to the saved GELU derivative only (AUX_DGELU / MULAUX)");
     MH_CHECK_ARG(!(flags & MH_GEMM_COLSUM) || colsum, "mh_gemm_fp8: colsum flag without pointer");
     MH_CHECK_ARG(!c8 || (!(flags & MH_GEMM_OUT_F32) && c8_scale && ldc8 % 8 == 0 && (uintptr_t)c8 % 8 == 0),
                  "mh_gemm_fp8: the fp8 output copy needs a bf16-output epilogue, a scale and ldc8 %% 8 == 0");

@@ -218,6 +218,8 @@ extern "C" int mh_gemm_grouped_check(int layout, const MhGemmProblem* problems_h
         MH_CHECK_ARG(!(fl & (MH_GEMM_DGELU | MH_GEMM_MULAUX)) || (q.aux_in && q.ldaux % 8 == 0), "mh_gemm_grouped[%d]: aux_in / ldaux", i);
         MH_CHECK_ARG(!(fl & MH_GEMM_AUX_DGELU) || ((fl & MH_GEMM_GELU) && q.aux_out), "mh_gemm_grouped[%d]: aux_dgelu needs GELU + aux_out", i);
         MH_CHECK_ARG(!(fl & MH_GEMM_GELU) || !q.aux_out || q.ldaux % 8 == 0, "mh_gemm_grouped[%d]: ldaux %% 8", i);
+        MH_CHECK_ARG(!(fl & MH_GEMM_AUX_U8) || ((fl & (MH_GEMM_AUX_DGELU | MH_GEMM_MULAUX)) && !(fl & MH_GEMM_DGELU)),
+                     "mh_gemm_grouped[%d]: MH_GEMM_AUX_U8 applies to the saved GELU derivative only", i);
         MH_CHECK_ARG(!((fl & MH_GEMM_DGELU) && (fl & MH_GEMM_MULAUX)), "mh_gemm_grouped[%d]: dgelu and mulaux exclude each other", i);
         MH_CHECK_ARG(!(fl & MH_GEMM_COLSUM) || q.colsum, "mh_gemm_grouped[%d]: colsum flag without pointer", i);
         // operand extents as the buffer descriptors will see them (rows beyond M / N and K rows beyond K read as zero)

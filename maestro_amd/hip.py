@@ -17,7 +17,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libmaestro_hip.so"
 _lib = None
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-OUT_F32, BIAS, GELU, RESIDUAL, DGELU, ATOMIC, COLSUM, AUX_DGELU, MULAUX, C8_E5M2 = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+OUT_F32, BIAS, GELU, RESIDUAL, DGELU, ATOMIC, COLSUM, AUX_DGELU, MULAUX, C8_E5M2, AUX_U8 = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
 
 
 class HipExtensionError(RuntimeError):

@@ -113,3 +113,41 @@ def test_gemm_bad_arguments_fail_loudly():
     A = torch.zeros(8, 12, device=dev, dtype=torch.bfloat16)
     with pytest.raises(hip.HipExtensionError):
         hip.gemm(0, 8, 8, 12, A, 12, A, 12, torch.zeros(8, 8, device=dev), 8, hip.OUT_F32)  # K % 8
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 768, 256), (1000, 1536, 192)])
+def test_saved_gelu_derivative_as_bytes(M, N, K):
+    """``MH_GEMM_AUX_U8``: the GELU derivative saved by the fc1 epilogue as one byte per element (code = round((d + 0.13) * 200))
+    decodes to the bf16 one within half a step (0.0025) + bf16 rounding, the activation output is unchanged, and the backward's
+    ``MULAUX`` epilogue reading the bytes equals the product with the decoded values."""
+    from maestro_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(M)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)  # noqa: N806
+    B = (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)  # noqa: N806
+    bias = torch.randn(N, generator=g).to(dev)
+    act16, act8 = (torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(2))
+    aux16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    aux8 = torch.zeros(M, N, dtype=torch.uint8, device=dev)
+    fl = hip.BIAS | hip.GELU | hip.AUX_DGELU
+    hip.gemm(hip.GEMM_NT, M, N, K, A, K, B, K, act16, N, fl, bias=bias, aux_out=aux16, ldaux=N)
+    hip.gemm(hip.GEMM_NT, M, N, K, A, K, B, K, act8, N, fl | hip.AUX_U8, bias=bias, aux_out=aux8, ldaux=N)
+    torch.cuda.synchronize()
+    assert torch.equal(act16.view(torch.int16), act8.view(torch.int16))
+    dec = aux8.float() / 200.0 - 0.13
+    assert (dec - aux16.float()).abs().max() <= 0.0025 + 2 ** -8 * 1.13 + 1e-6
+    assert float(aux16.float().min()) < -0.1 and float(aux16.float().max()) > 1.1      # the whole range of GELU' is exercised
+    # backward: dh = (dY W) * GELU'
+    dy = (torch.randn(M, K, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    W = (torch.randn(K, N, generator=g) * 0.5).to(torch.bfloat16).to(dev)  # noqa: N806
+    rows = (M + 63) // 64
+    d16, d8 = (torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(2))
+    cs16, cs8 = torch.zeros(rows, N, device=dev), torch.zeros(rows, N, device=dev)
+    dec16 = dec.to(torch.bfloat16)          # (exactly representable: at most 8 significant bits ... not quite: compare numerically)
+    hip.gemm(hip.GEMM_NN, M, N, K, dy, K, W, N, d8, N, hip.MULAUX | hip.COLSUM | hip.AUX_U8, aux_in=aux8, ldaux=N, colsum=cs8)
+    hip.gemm(hip.GEMM_NN, M, N, K, dy, K, W, N, d16, N, hip.MULAUX | hip.COLSUM, aux_in=dec16, ldaux=N, colsum=cs16)
+    torch.cuda.synchronize()
+    assert (d8.float() - d16.float()).abs().max() <= 2e-2 * d16.float().abs().max()
+    assert (cs8 - cs16).abs().max() <= 2e-2 * cs16.abs().max()
+    with pytest.raises(hip.HipExtensionError):
+        hip.gemm(hip.GEMM_NT, M, N, K, A, K, B, K, act8, N, hip.BIAS | hip.GELU | hip.AUX_U8, bias=bias, aux_out=aux8, ldaux=N)
