@@ -527,6 +527,7 @@ class EngineBase:
         self._graphs, self._seen, self._ready_spans = {}, {}, []
         self._inputs = {}           # per batch key: last device address, or the engine-owned staging copy
         self.side_streams = [torch.cuda.Stream(device=device) for _ in range(max(0, n_side_streams))]
+        self._wgrad_stream = torch.cuda.Stream(device=device)   # plan "ovl": deferred weight gradients under the next segment
 
     def _stable_inputs(self, batch: dict) -> dict:
         """The captured launch segments bake device addresses in.  A tensor that keeps its address from step to step (a
@@ -1171,6 +1172,8 @@ class MAEEngine(EngineBase):
             plan = "enc" if self.wgrad_mode == "deferred" or sum(tiles) // n_seg >= self.WGRAD_MIN_TILES else "fused"
         else:
             plan = "all" if self.wgrad_mode == "deferred" or sum(tiles) >= self.WGRAD_MIN_TILES else "fused"
+            if plan == "all" and os.environ.get("MAESTRO_WGRAD_OVERLAP", "0") == "1":
+                plan = "ovl"     # per-segment grouped launches, each on a side stream UNDER the next segment's dgrad chain
         self._wgrad_plans[(self.wgrad_mode, hooked)] = plan
         return plan
 
@@ -1192,6 +1195,29 @@ class MAEEngine(EngineBase):
         table[1].launch()   # LayerNorm / bias parameter gradients of the same layers: one batched column-sum launch
         table[0].launch()
 
+    def _with_overlapped_wgrads(self, fn, previous, own):
+        """Plan "ovl": the weight gradients of the PREVIOUS segment run on a side stream under this segment's dgrad chain (their
+        operands -- the per-layer dY / activation buffers -- are final, nothing here writes them); the last segment also issues
+        its own at its end.  The grouped TN launch is one workgroup per 256 x 256 tile with a 128 KiB ring, the dgrad chain two
+        64 KiB workgroups per CU: a CU runs one or the other, so the side stream fills the CUs that the chain's small launches
+        and kernel tails leave idle instead of following the chain as 2.6 ms of its own."""
+        def run():
+            if previous and self.multi_stream:
+                main = torch.cuda.current_stream()
+                side = self._wgrad_stream
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._launch_wgrads(previous)
+                fn()
+                main.wait_stream(side)
+            else:
+                if previous:
+                    self._launch_wgrads(previous)
+                fn()
+            if own:
+                self._launch_wgrads(own)
+        return run
+
     def _enc_cuts(self) -> list:
         # encoder side: with a gradient hook (data parallel) cut it into layer ranges so the all-reduce of the finished
         # slices overlaps the remaining layers (~85 % of the parameters live in the group encoders)
@@ -1199,7 +1225,8 @@ class MAEEngine(EngineBase):
         # (measured at N = 1, C3: +2.3 % for three), every missing one leaves more gradient bytes to reduce after the backward
         depth = max(st.depth for st in self.enc.values())
         n = max(1, min(4, int(os.environ.get("MAESTRO_ENC_CUTS", "3"))))
-        if self.grad_hook is None or depth < 3 or n == 1:
+        cut = self.grad_hook is not None or getattr(self, "_plan", None) == "ovl"
+        if not cut or depth < 3 or n == 1:
             return [depth, 0]
         return [depth] + [depth - (i * depth) // n for i in range(1, n)] + [0]
 
@@ -1218,14 +1245,20 @@ class MAEEngine(EngineBase):
         sfx = f":{plan}:{'h' if self.grad_hook is not None else 'n'}"   # graphs are specific to the launch plan
         if self.fp8 is not None and self.fp8.dgrad:
             sfx += ":f8" if self.fp8.grad_ready else ":cal"       # (the first backward calibrates the gradient scales in bf16)
+        cuts = self._enc_cuts()
+        # (name, launches, deferred weight gradients of the segment)
+        segs = [("bwd_dec", self._bwd_decoder_side, [(st, 0, st.depth) for st in self.dec.values()])]
+        if self.joint is not None:
+            segs.append(("bwd_joint", self._bwd_joint, [(self.joint, 0, self.joint.depth)]))
+        for i in range(len(cuts) - 1):
+            segs.append((f"bwd_enc{i}", lambda hi=cuts[i], lo=cuts[i + 1], first=(i == 0), last=(i == len(cuts) - 2):
+                         self._bwd_encoder_side(hi, lo, first, last),
+                         [(st, min(cuts[i + 1], st.depth), min(cuts[i], st.depth)) for st in self.enc.values()]))
         with self._tuning_pass("backward"):
-            self._segment("bwd_dec" + sfx, key, self._bwd_decoder_side)
-            if self.joint is not None:
-                self._segment("bwd_joint" + sfx, key, self._bwd_joint)
-            cuts = self._enc_cuts()
-            for i in range(len(cuts) - 1):
-                self._segment(f"bwd_enc{i}" + sfx, key, lambda hi=cuts[i], lo=cuts[i + 1], first=(i == 0), last=(i == len(cuts) - 2):
-                              self._bwd_encoder_side(hi, lo, first, last))
+            for i, (name, fn, items) in enumerate(segs):
+                if plan == "ovl":
+                    fn = self._with_overlapped_wgrads(fn, segs[i - 1][2] if i else None, items if i == len(segs) - 1 else None)
+                self._segment(name + sfx, key, fn)
         if self.fp8 is not None:
             self.fp8.end_of_backward()      # next step's e5m2 gradient scales from this backward's absmax values
 
@@ -1254,7 +1287,7 @@ class MAEEngine(EngineBase):
                     self._grads_ready(m.embed_to_rec[s.embed])
                 if part == "pre":
                     return
-                dx0, _ = st.backward(dx, defer=self._plan in ("all", "enc"))
+                dx0, _ = st.backward(dx, defer=self._plan in ("all", "enc", "ovl"))
                 side_post(g, gbuf, st, dx0)
             return run
 
@@ -1283,7 +1316,7 @@ class MAEEngine(EngineBase):
 
         if self.dec_set is not None:
             self._run_parallel([side(g, "pre") for g in self.groups])
-            res = self.dec_set.backward([st.dxa for st in self.dec_set.stacks], defer=self._plan in ("all", "enc"))
+            res = self.dec_set.backward([st.dxa for st in self.dec_set.stacks], defer=self._plan in ("all", "enc", "ovl"))
             self._dec_state = {g.name: r for g, r in zip(self.groups, res)}
             self._run_parallel([side(g, "post") for g in self.groups])
         else:
@@ -1294,9 +1327,9 @@ class MAEEngine(EngineBase):
     def _bwd_joint(self) -> None:
         jt = self.joint
         if self.joint_set is not None:
-            self._djoint = self.joint_set.backward([jt.dxa], defer=self._plan in ("all", "enc"))[0][0]
+            self._djoint = self.joint_set.backward([jt.dxa], defer=self._plan in ("all", "enc", "ovl"))[0][0]
         else:
-            self._djoint, _ = jt.backward(jt.dxa, defer=self._plan in ("all", "enc"))
+            self._djoint, _ = jt.backward(jt.dxa, defer=self._plan in ("all", "enc", "ovl"))
         self._grads_ready(jt.t.norm)
         if self._plan == "enc":
             self._launch_wgrads([(jt, 0, jt.depth)])
