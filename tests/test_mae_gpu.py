@@ -179,6 +179,31 @@ def test_graph_replay_and_streams_match_eager(golden_dir, wgrad):
     assert set(eng._graphs) >= {"forward"} | {f"{seg}:{plan}:n" for seg in ("bwd_dec", "bwd_joint", "bwd_enc0")}
 
 
+def test_overlapped_wgrad_plan_matches_inline(golden_dir, monkeypatch):
+    """Opt-in plan ``MAESTRO_WGRAD_OVERLAP=1``: five backward segments, every segment's grouped weight gradients on a side
+    stream under the next segment's dgrad chain (eager, captured and replayed) -- same gradients as the in-line plan."""
+    monkeypatch.setenv("MAESTRO_WGRAD_OVERLAP", "1")
+    dev, case, gold, ds, oracle, model, batch, noise, struct = _setup("c3_aerial_s2", golden_dir)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    eng = model.engine(case["B"], dev, loss="l2_norm")
+    eng.wgrad_mode = "fused"
+    eng.use_graphs, eng.multi_stream = False, False
+    eng.forward(dbatch, noise=noise, struct=struct)
+    eng.zero_grad()
+    eng.backward()
+    ref_grad = eng.store.grad.clone()
+    eng.use_graphs, eng.multi_stream, eng.wgrad_mode = True, True, "deferred"
+    for it in range(3):
+        eng.forward(dbatch, noise=noise, struct=struct)
+        eng.zero_grad()
+        eng.backward()
+        torch.cuda.synchronize()
+        assert eng._plan == "ovl"
+        rel = ((eng.store.grad - ref_grad).norm() / ref_grad.norm()).item()
+        assert rel < 1e-4, (it, rel)
+    assert {"bwd_dec:ovl:n", "bwd_joint:ovl:n", "bwd_enc0:ovl:n"} <= set(eng._graphs)
+
+
 @pytest.mark.parametrize("interpolate", ["nearest", "bilinear", "bicubic"])
 def test_input_resize_staging_matches_oracle(golden_dir, interpolate):
     """Rasters arriving at another resolution are resized on the GPU (mim.py:427-432) exactly like the oracle/reference."""
