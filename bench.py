@@ -339,7 +339,8 @@ def main() -> None:
     marks.append(ev)
     sync()
     elapsed = time.perf_counter() - t0
-    step_ms = sorted(a.elapsed_time(b) for a, b in zip(marks, marks[1:]))
+    step_seq = [a.elapsed_time(b) for a, b in zip(marks, marks[1:])]
+    step_ms = sorted(step_seq)
     loss_val = float(loss.item())   # the engine's loss buffer is static: read it before the roofline leg runs more steps
     # Roofline leg: the same steps once more with HIP events around every MFMA-kernel launch on its stream (event
     # pairs cannot be recorded inside a captured graph, so these steps are launched eagerly; kernels are identical).
@@ -369,7 +370,9 @@ def main() -> None:
             "metric": f"MAE-{args.phase} tiles/sec", "value": round(value, 2), "unit": "tiles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "step_ms": {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3),
-                        "max": round(step_ms[-1], 3), "how": "HIP events on the main stream at every step boundary (this rank)"},
+                        "max": round(step_ms[-1], 3), "first": round(step_seq[0], 3),
+                        "how": "HIP events on the main stream at every step boundary (this rank); first = the step right after "
+                               "the barrier + synchronize (empty GPU queue: the host's issue latency is exposed once)"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic" if not args.from_host else "synthetic, fed from pinned host memory every step (PCIe-inclusive)",
             "config": {"workload": f"{args.config}: {w['desc']}", "tiles_per_gpu": args.batch,
