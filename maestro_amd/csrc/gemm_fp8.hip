@@ -16,6 +16,7 @@
 //         consecutive bytes; C / D as every 16 x 16 MFMA: column l & 15, rows 4 (l >> 4) + r.
 #include "gemm_common.hpp"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -211,7 +212,7 @@ extern "C" int mh_gemm_fp8(int M, int N, int K, const void* A8, int lda, int a_f
     const long tiles256 = (long)ceil_div(M, 256) * ceil_div(N, 256), tiles128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
     const char* force = getenv("MH_FP8_TILE");       // "256", "128" (two-stage ring), "128d" (four-stage ring)
     const bool big = force ? force[0] == '2' : (tiles256 >= 768 && K >= 2048);
-    const bool deep = force ? (force[0] == '1' && force[3] == 'd') : (tiles128 > 128 && tiles128 <= 256 && K >= 2048);   // (256 CUs: at most one tile per CU)
+    const bool deep = force ? strcmp(force, "128d") == 0 : (tiles128 > 128 && tiles128 <= 256 && K >= 2048);   // (256 CUs: at most one tile per CU)
     if (big) launch_fp8<T8_256>(p, a_format, (hipStream_t)stream);
     else if (deep) launch_fp8<T8_128D>(p, a_format, (hipStream_t)stream);
     else launch_fp8<T8_128>(p, a_format, (hipStream_t)stream);
