@@ -210,7 +210,9 @@ class SSLModule(_Base):
                 p.requires_grad = False
         else:
             self.ema_model = None
-        self._anchor = nn.Parameter(torch.zeros(()), requires_grad=True)  # autograd entry point of the engine
+        # autograd entry point of the engine: a plain leaf tensor, NOT a registered parameter -- ``state_dict()`` (what
+        # Lightning's ModelCheckpoint saves) then holds exactly the reference module's keys, and no optimizer ever sees it
+        self._anchor = torch.zeros((), requires_grad=True)
         self.save_hyperparameters(ignore=["datasets"])
         if not hasattr(self, "trainer") or getattr(self, "_trainer", None) is None:
             try:

@@ -609,6 +609,21 @@ def run_ckpt(ref, ours) -> None:
     print(f"[ckpt] maestro_amd-written checkpoint loaded into the reference SSLModule with strict=True "
           f"({len(back['state_dict'])} tensors, mask = {back['hyper_parameters']['mask']})")
 
+    # (3) the one-line swap of maestro/run_experiment.py:39-40: OUR SSLModule built from the REFERENCE's own config objects
+    #     (DatasetsConfig / MaskConfig / ModelConfig instances, exactly what run_experiment passes) -- duck-typed, no conversion
+    from maestro.conf.model import ModelConfig as RefModelConfig
+    for fusion, inter in (("group", 3), ("mod", 1), ("shared", 0), ("monotemp", 0)):
+        cfg = RefModelConfig(model_size="tiny", fusion_mode=fusion, inter_depth=inter, use_ema=False)
+        theirs = ref.model.SSLModule(datasets=ds_ref, mask=mask_ref, **vars(cfg))
+        swapped = OurModule(datasets=ds_ref, mask=mask_ref, **vars(cfg))
+        a = {k: tuple(v.shape) for k, v in theirs.state_dict().items()}
+        b = {k: tuple(v.shape) for k, v in swapped.state_dict().items()}
+        assert a == b, (fusion, sorted(set(a) ^ set(b))[:5])
+        assert swapped.norm_bands == theirs.norm_bands and swapped.model.mask_ratio == theirs.model.mask_ratio
+        assert swapped.model.grid_size == theirs.model.grid_size and swapped.model.len_bands == theirs.model.len_bands
+    print(f"[ckpt] maestro_amd SSLModule built from the reference's config objects: state-dict keys and shapes equal the "
+          f"reference module's for all four fusion modes ({len(a)} tensors)")
+
 
 def layer_vectors(ref) -> dict:
     """Known-answer vectors for the directly importable reference layers (embed.py / utils.py)."""

@@ -22,6 +22,7 @@ def test_checkpoints_go_both_ways(tmp_path, golden_dir):
                        timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "loaded into the reference SSLModule with strict=True" in r.stdout
+    assert "built from the reference's config objects" in r.stdout       # the one-line import swap of run_experiment.py
     fresh = gzip.decompress((tmp_path / "ref_written.ckpt.gz").read_bytes())
     stored = gzip.decompress((golden_dir / "ref_written.ckpt.gz").read_bytes())
     assert len(fresh) == len(stored)          # same tensors, same pickled hyper-parameters as the committed fixture
