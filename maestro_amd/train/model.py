@@ -320,6 +320,17 @@ class SSLModule(_Base):
         log_inputs, log_preds, log_targets = self.compute_logs_rec(batch, engine, self._ssl_phase(), stage)
         return {"loss": loss, "log_inputs": log_inputs, "log_preds": log_preds, "log_targets": log_targets}
 
+    def log_metric(self, name: str, value) -> None:
+        """Epoch-level metric (``maestro/train/base.py:153-167``)."""
+        self.log(name=name, value=value, on_step=False, on_epoch=True, prog_bar=True, logger=True, sync_dist=True)
+
+    def log_step(self, name: str, value, ssl_phase: str, stage: str) -> None:
+        """Step-level training metric (``maestro/train/base.py:169-187``): logged for the train stage only."""
+        if stage != "train":
+            return
+        self.log(name=f"{ssl_phase}_{name}/step_{stage}", value=value, on_step=True, on_epoch=False, prog_bar=True, logger=True,
+                 sync_dist=True)
+
     def compute_loss_pred(self, engine, stage: str) -> torch.Tensor:
         """``loss_pred`` of the last supervised forward (``base.py:98-151``; computed on the GPU by mh_ce_loss / mh_bce_loss)."""
         loss = _EngineLoss.apply(self._anchor, engine, engine.loss_acc)

@@ -358,3 +358,21 @@ def test_scheduler_covers_every_output_once():
                     cov[m0 // 128: (m0 + h) // 128, n0 // 128: (n0 + w) // 128] += 1
             assert (cov == 1).all(), (shapes, workers)
         assert makespan > 0
+
+
+def test_module_log_helpers_and_state_dict_surface():
+    """``log_metric`` / ``log_step`` (``maestro/train/base.py:153-187``) forward to ``self.log`` with the reference's arguments;
+    the autograd anchor of the engine bridge is neither a parameter nor a state-dict entry (Lightning's own checkpoints then
+    carry exactly the reference module's keys)."""
+    mod = SSLModule(datasets=treesat(), mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=0,
+                    model="mae", model_size="tiny")
+    seen = []
+    mod.log = lambda **k: seen.append(k)
+    mod.log_metric("pretrain_loss_rec/val", 1.5)
+    mod.log_step("loss_rec", 2.0, "pretrain", "train")
+    mod.log_step("loss_rec", 2.0, "pretrain", "val")          # only the train stage logs per step
+    assert seen == [dict(name="pretrain_loss_rec/val", value=1.5, on_step=False, on_epoch=True, prog_bar=True, logger=True, sync_dist=True),
+                    dict(name="pretrain_loss_rec/step_train", value=2.0, on_step=True, on_epoch=False, prog_bar=True, logger=True,
+                         sync_dist=True)]
+    assert "_anchor" not in mod.state_dict() and all(n != "_anchor" for n, _ in mod.named_parameters())
+    assert mod._anchor.requires_grad and mod._anchor.is_leaf
