@@ -79,28 +79,21 @@ __device__ __forceinline__ void gelu_cdf_pdf(float x, float& cdf, float& pdf) {
     cdf = 0.5f * (1.f + copysignf(erf_abs, x));
     pdf = 0.3989422804014327f * e;
 }
-// Four elements at once, written as whole-vector expressions so that the polynomial, the products and the affine steps
-// compile to packed v_pk_fma_f32 / v_pk_mul_f32 (two floats per instruction); only |x|, rcp, exp2 and the sign transfer stay
-// per element.  Same formula and rounding as gelu_cdf_pdf (the GEMM epilogues are VALU-bound at K = 768: a 64 x 64 wave
-// tile holds 64 outputs per lane against ~6100 MFMA cycles of main loop).
+// Four elements at once for the GEMM epilogues, where this arithmetic is NOT hidden: at K = 768 the fc1 GEMM ran 49 us with a plain
+// bias epilogue and 67 us with the GELU (scripts/bench_gelu_cost.py).  Abramowitz-Stegun 7.1.25 (three terms, |error| <= 2.5e-5 on
+// erf: far below what the bf16 activation -- 4e-3 relative -- and the byte-coded derivative -- 2.5e-3 absolute -- resolve) with the
+// constants folded: 15 issue slots per element (rcp and exp2 count two each) instead of 19 for the five-term 7.1.26 above.
+//   z = |x| / sqrt2, t = 1 / (1 + p z), h = 0.5 (a1 t + a2 t^2 + a3 t^3) exp(-z^2) = 1 - Phi(|x|);  Phi(x) = x >= 0 ? 1 - h : h
 __device__ __forceinline__ void gelu_cdf_pdf4(const f32x4 x, f32x4& cdf, f32x4& pdf) {
-    const f32x4 ax = {fabsf(x[0]) * 0.70710678118654752f, fabsf(x[1]) * 0.70710678118654752f,
-                      fabsf(x[2]) * 0.70710678118654752f, fabsf(x[3]) * 0.70710678118654752f};
-    const f32x4 den = ax * 0.3275911f + 1.f;
-    const f32x4 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1]), __builtin_amdgcn_rcpf(den[2]),
-                     __builtin_amdgcn_rcpf(den[3])};
-    const f32x4 a = (ax * -1.4426950408889634f) * ax;
-    const f32x4 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1]), __builtin_amdgcn_exp2f(a[2]),
-                     __builtin_amdgcn_exp2f(a[3])};
-    f32x4 poly = t * 1.061405429f - 1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t - 0.284496736f;
-    poly = poly * t + 0.254829592f;
-    const f32x4 erf_abs = 1.f - (poly * t) * e;
-    const f32x4 erf = {copysignf(erf_abs[0], x[0]), copysignf(erf_abs[1], x[1]), copysignf(erf_abs[2], x[2]),
-                       copysignf(erf_abs[3], x[3])};
-    cdf = erf * 0.5f + 0.5f;
-    pdf = e * 0.3989422804014327f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(x[i]), 0.47047f * 0.70710678118654752f, 1.f));
+        const float e = __builtin_amdgcn_exp2f((x[i] * x[i]) * (-0.5f * 1.4426950408889634f));      // exp(-x^2 / 2)
+        const float poly = __builtin_fmaf(__builtin_fmaf(0.5f * 0.7478556f, t, 0.5f * -0.0958798f), t, 0.5f * 0.3480242f);
+        const float h = (poly * t) * e;
+        cdf[i] = x[i] >= 0.f ? 1.f - h : h;
+        pdf[i] = e * 0.3989422804014327f;
+    }
 }
 __device__ __forceinline__ f32x4 gelu_erf4(const f32x4 x) {
     f32x4 cdf, pdf;
