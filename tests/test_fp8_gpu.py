@@ -303,3 +303,34 @@ def test_gemm_fp8_dgrad_epilogue(dev):
         diff = (c8.int() - want).abs()          # the copy is cast from the fp32 value, the comparison from its bf16 rounding
         assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 0.1
         assert abs(float(amax.max()) - float(C8.float().abs().max())) <= 2 ** -7 * float(amax.max())
+
+
+@pytest.mark.parametrize("dgrad", ["0", "1"])
+def test_fp8_under_the_exchange_plan(dev, monkeypatch, dgrad):
+    """The fp8 path inside the data-parallel launch plan (gradient hooks, five backward segments, per-segment grouped weight
+    gradients, two-part AdamW; no process group: ``exchange=True`` keeps the plan and skips the collectives): every gradient
+    slice is reported exactly once per step, and the loss trajectory equals the plain fp8 loop's."""
+    import maestro_amd.conf as conf
+    from maestro_amd.ssl import mae as pmae
+    from maestro_amd.train.trainer import PretrainLoop, synthetic_batch
+    from oracle.gen_golden import build_datasets, case_table
+    monkeypatch.setenv("MAESTRO_FP8_DGRAD", dgrad)
+    case = dict(case_table()["c3_aerial_s2"])
+    ds = build_datasets(case, conf)
+    kw = dict(fusion_mode="group", inter_depth=1, depth=4, **COMMON)
+    runs = []
+    for exchange in (False, True):
+        torch.manual_seed(5)
+        model = pmae.mae_small(datasets=ds, mask=conf.MaskConfig(), **kw)
+        loop = PretrainLoop(model, 4, dev, total_steps=8, dtype="fp8", exchange=exchange or None, bucket_mb=1)
+        assert loop.engine.fp8 is not None and (loop.sync is not None) == exchange
+        batch = synthetic_batch(ds.dataset, 4, dev, seed=3)
+        torch.manual_seed(11)
+        losses = [float(loop.step(batch).item()) for _ in range(5)]
+        if exchange:
+            covered = sorted(loop.sync.launched)
+            assert covered[0][0] == 0 and covered[-1][1] == loop.engine.store.grad_all.numel()
+            assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), "buckets must tile the gradient buffer"
+        runs.append(losses)
+    assert all(l == l for l in runs[0] + runs[1])
+    assert all(abs(a - b) < 2e-3 * abs(a) for a, b in zip(*runs)), runs      # same arithmetic; the wgrad launches are grouped differently
