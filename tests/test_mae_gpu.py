@@ -501,3 +501,25 @@ def test_identity_enc_to_dec_when_widths_match(golden_dir, inter_depth):
             got, want = eng.store.g(p).cpu(), ograds[k]
             err, ref = (got - want).double().norm().item(), want.double().norm().item()
             assert err <= GRAD_TOL * ref + 1e-5 * gmax * want.numel() ** 0.5, (k, err / max(ref, 1e-12))
+
+
+@pytest.mark.parametrize("name", ["bg_aerial_s2", "bg_ts_monotemp"])
+def test_band_groups_under_the_exchange_plan(golden_dir, name):
+    """Several band-groups per modality inside the data-parallel launch plan (no process group: the plan without the
+    collectives): the reported gradient slices tile the buffer exactly once per step although a modality's band-groups share
+    its patch-embed / pixelify / mask-token parameters, and the losses equal the plain loop's."""
+    from maestro_amd.train.trainer import PretrainLoop
+    dev, case, gold, ds, oracle, model, batch, noise, struct = _setup(name, golden_dir)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    runs = []
+    for exchange in (False, True):
+        model.load_state_dict(oracle.state_dict(), strict=True)
+        model._engine = None
+        loop = PretrainLoop(model, case["B"], dev, total_steps=8, exchange=exchange or None, bucket_mb=1)
+        torch.manual_seed(21)
+        runs.append([float(loop.step(dbatch).item()) for _ in range(4)])
+        if exchange:
+            covered = sorted(loop.sync.launched)
+            assert covered[0][0] == 0 and covered[-1][1] == loop.engine.store.grad_all.numel()
+            assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), covered
+    assert all(abs(a - b) < 1e-3 * abs(a) for a, b in zip(*runs)), runs
