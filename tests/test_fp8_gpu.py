@@ -334,3 +334,48 @@ def test_fp8_under_the_exchange_plan(dev, monkeypatch, dgrad):
         runs.append(losses)
     assert all(l == l for l in runs[0] + runs[1])
     assert all(abs(a - b) < 2e-3 * abs(a) for a, b in zip(*runs)), runs      # same arithmetic; the wgrad launches are grouped differently
+
+
+def test_fp8_on_the_lightning_surface(dev, monkeypatch):
+    """``MAESTRO_DTYPE=fp8`` under ``SSLModule`` as Lightning drives it (``training_step`` -> ``loss.backward()`` -> a TORCH
+    optimizer that changes the masters behind the engine's back): the e4m3 weight shadows are rebuilt from the updated masters
+    with freshly derived scales at the next forward, and training makes progress."""
+    from types import SimpleNamespace
+
+    import maestro_amd.conf as conf
+    from maestro_amd.train.model import SSLModule
+    from maestro_amd.train.trainer import synthetic_batch
+    from oracle.gen_golden import build_datasets, case_table
+    monkeypatch.setenv("MAESTRO_DTYPE", "fp8")
+    ds = build_datasets(dict(case_table()["c3_aerial_s2"]), conf)
+    torch.manual_seed(0)
+    mod = SSLModule(datasets=ds, mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=1, model="mae",
+                    model_size="small", loss="l2_norm", use_ema=False)
+    mod.trainer = SimpleNamespace(ssl_phase="pretrain", train_dataloader=SimpleNamespace(batch_size=2), accumulate_grad_batches=1,
+                                  num_nodes=1, num_devices=1, base_lr=3e-3, wd=0.01, b1=0.9, b2=0.99, final_factor=1e7,
+                                  estimated_stepping_batches=20, max_epochs=5)
+    batch = synthetic_batch(ds.dataset, 2, dev)
+    cfg = mod.configure_optimizers()
+    opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+    losses = []
+    for step in range(5):
+        torch.manual_seed(11)
+        out = mod.training_step(batch, step)
+        opt.zero_grad(set_to_none=True)
+        out["loss"].backward()
+        opt.step()
+        sched.step()
+        losses.append(out["loss"].item())
+    eng = mod.model._engine
+    assert eng.fp8 is not None and all(st.f8 is not None for st in eng._all_stacks())
+    assert losses[-1] < losses[0], losses
+    mod.training_step(batch, 99)            # the forward after the last torch update re-quantises every weight
+    torch.cuda.synchronize()
+    f0 = eng.enc["aerial"].f8[0]
+    w = eng.enc["aerial"].t.layers[0][0].to_qkv.weight.detach()
+    scale = float(eng.fp8.wsc.scale[f0["sw_qkv"]])
+    amax = float(w.abs().max())
+    import math
+    assert scale == 2.0 ** (math.floor(math.log2(448.0 / amax)) - 1)
+    want = (w.float() * scale).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(f0["w_qkv"], want), "e4m3 weight shadow is stale after a torch optimizer step"
