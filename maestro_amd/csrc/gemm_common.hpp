@@ -151,7 +151,8 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                 f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * 68 + c);
                 f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * 68 + c + 4);
                 if (m < p.M && n < p.N) {
-                    lo = lo * alpha + b_lo; hi = hi * alpha + b_hi;
+                    if (p.descale_a) { lo = lo * alpha + b_lo; hi = hi * alpha + b_hi; }   // fp8 operands: per-tensor dequantisation
+                    else { lo += b_lo; hi += b_hi; }
                     if (p.flags & MH_GEMM_GELU) {
                         f32x4 c_lo, d_lo, c_hi, d_hi;      // CDF and PDF of the pre-activation (one exp2 + one rcp per element)
                         gelu_cdf_pdf4(lo, c_lo, d_lo);
@@ -191,7 +192,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                         lo *= gelu_erf_grad4(h_lo);
                         hi *= gelu_erf_grad4(h_hi);
                     }
-                    cs_lo += lo; cs_hi += hi;
+                    if (p.flags & MH_GEMM_COLSUM) { cs_lo += lo; cs_hi += hi; }   // (uniform branch: the fc1 epilogue is VALU-bound)
                     u32x4 pk = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
                     *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = pk;
                     if (p.c8) {
