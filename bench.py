@@ -390,7 +390,7 @@ def main() -> None:
             out["roofline"] = timer.roofline(MFMA_PEAK_TFLOPS)
             if out["roofline"]["kernel"] == "gemm_fp8_kernel":     # price an fp8 kernel against the fp8 MFMA peak
                 out["roofline"].update(peak=FP8_PEAK_TFLOPS, frac=round(out["roofline"]["achieved"] / FP8_PEAK_TFLOPS, 4))
-            elif args.dtype == "fp8":
+            elif args.dtype == "fp8" and timer.flops.get("gemm_fp8_kernel"):
                 tot = timer.totals()
                 ach = timer.flops["gemm_fp8_kernel"] / (tot["gemm_fp8_kernel"] * 1e-3) / 1e12
                 out["roofline_fp8_kernel"] = {"bound": "mfma", "kernel": "gemm_fp8_kernel", "achieved": round(ach, 1),

@@ -50,6 +50,11 @@ int mh_version(void);
                                * BYTE per element, code = round((GELU' + 0.13) * 200): GELU' lies in [-0.129, 1.129], the step of
                                * 0.005 is about what bf16 resolves near 1; halves the derivative's HBM bytes (ldaux in bytes) */
 #define MH_GEMM_C8_E5M2 512   /* mh_gemm_fp8 only: the fp8 copy c8 of the output is e5m2 (a gradient: the next dgrad's A operand) */
+/* mh_gemm_fp8 only, at most one of them: force a tile / ring form instead of the library's size rule (experiments, tests).
+ * The library never reads the environment: every such choice is an argument (maestro_amd/hip.py maps MH_FP8_TILE onto these). */
+#define MH_GEMM_FP8_TILE_256 2048    /* 256 x 256, 8 waves */
+#define MH_GEMM_FP8_TILE_128 4096    /* 128 x 128, two-stage ring, two workgroups per CU */
+#define MH_GEMM_FP8_TILE_128D 8192   /* 128 x 128, four-stage ring */
 int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                  int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                  int ldaux, float* colsum, void* stream);
@@ -59,11 +64,12 @@ int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const 
  *   MH_TILE_DMA_256      256x256x32 tile, 8 waves, 4-stage LDS-DMA ring (gemm_dma.hip)
  *   MH_TILE_DMA_256x128 / MH_TILE_DMA_128x256   4 waves, 3-stage ring;   MH_TILE_DMA_128   128x128, 2 waves, 4-stage ring
  *   MH_TILE_DMA_128x4    128x128, four 64x64 waves, 4-stage ring (the register-staged kernel's geometry, DMA-fed)
+ *   MH_TILE_DMA_256_LOCKSTEP   MH_TILE_DMA_256 without the wave-group stagger (A/B experiments; bit-identical results)
  * The DMA tiles return -2 (nothing launched, error string untouched) when the problem does not qualify (K %% 32 != 0 with
  * a K-minor operand, operands beyond the 2 GiB buffer-descriptor range): pick another tile.  The host side times the
  * eligible tiles once per distinct (layout, M, N, K, flags) and remembers the fastest (maestro_amd/hip.py). */
 enum { MH_TILE_AUTO = -1, MH_TILE_REG_128 = 0, MH_TILE_DMA_256 = 1, MH_TILE_DMA_256x128 = 2, MH_TILE_DMA_128x256 = 3,
-       MH_TILE_DMA_128 = 4, MH_TILE_DMA_128x4 = 5 };
+       MH_TILE_DMA_128 = 4, MH_TILE_DMA_128x4 = 5, MH_TILE_DMA_256_LOCKSTEP = 6 };
 int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                       int ldaux, float* colsum, void* stream);

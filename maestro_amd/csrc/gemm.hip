@@ -11,7 +11,6 @@
 // columns of one row: bias/residual/aux are read and C is written with 8/16-byte vectors.
 // Split-K + fp32 atomics (LDS-transposed so each wave instruction adds 256 contiguous bytes) serve the wgrad.
 #include "gemm_common.hpp"
-#include <stdlib.h>
 
 namespace {
 
@@ -295,12 +294,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmParams p) {
 // Dispatch rule for the large-tile LDS-DMA kernel (gemm_dma.hip), from scripts/bench_tiles.py on MI355X: it wins (x1.05 to
 // x1.2, x1.8 on the K = 512 dgrad) for NT and NN problems whose 256x256 tiles fill the 256 CUs in whole waves (>= 90 % wave
 // efficiency: the M = 32768 decoder shapes); it loses when the tile count quantises badly (M = 8192 encoder shapes) and for
-// split-K wgrads (more splits -> more fp32 atomic passes).  MH_GEMM_DMA=0 disables it, MH_GEMM_DMA=1 forces it wherever it
-// is eligible (experiments).
+// split-K wgrads (more splits -> more fp32 atomic passes).  The library reads no environment: a caller that wants another
+// kernel passes an explicit tile to mh_gemm_bf16_tile (maestro_amd/hip.py maps MH_GEMM_DMA / MH_GEMM_TILE onto that).
 static bool prefer_dma(int layout, int M, int N, int K, int flags) {
-    const char* e = getenv("MH_GEMM_DMA");
-    if (e && e[0] == '0') return false;
-    if (e && e[0] == '1') return true;
     if (layout == 2 || (flags & MH_GEMM_ATOMIC) || K % 32 != 0 || K < 256) return false;
     const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256);
     if (tiles < 256) return false;
@@ -311,7 +307,7 @@ static bool prefer_dma(int layout, int M, int N, int K, int flags) {
 extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                                  void* C, int ldc, int flags, const float* bias, const float* res, int ldr,
                                  const void* aux_in, void* aux_out, int ldaux, float* colsum, void* stream) {
-    MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_DMA_128x4, "mh_gemm_bf16: tile %d", tile);
+    MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_DMA_256_LOCKSTEP, "mh_gemm_bf16: tile %d", tile);
     MH_CHECK_ARG(layout >= 0 && layout <= 2, "mh_gemm_bf16: layout %d", layout);
     MH_CHECK_ARG(M > 0 && N > 0 && K > 0, "mh_gemm_bf16: empty problem %d %d %d", M, N, K);
     MH_CHECK_ARG(A && B && C, "mh_gemm_bf16: null operand");

@@ -15,7 +15,6 @@
 //          fragments by ds_read_b64_tr_b16 (hardware transpose)
 // Out-of-range rows / K rows read as zero through the buffer descriptor's extent (no predication anywhere).
 #include "gemm_ring.hpp"
-#include <stdlib.h>
 
 namespace {
 
@@ -197,13 +196,8 @@ __global__ __launch_bounds__(T::NT) void gemm_dma_grouped_tn_kernel(const MhGrou
     gemm_dma_tile<T, true, true, 1, STAGGER>(p, tile_m, tile_n, 0, g.K, smem);
 }
 
-static bool stagger_on() {
-    const char* e = getenv("MH_DMA_STAGGER");
-    return !(e && e[0] == '0');
-}
-
 template <class T>
-int launch_dma(int layout, GemmParams& p, hipStream_t s) {
+int launch_dma(int layout, GemmParams& p, hipStream_t s, bool stagger = true) {
     const int M = p.M, N = p.N, K = p.K;
     const bool a_kmajor = layout == 2, b_kmajor = layout != 0;
     p.tiles_m = ceil_div(M, T::BM); p.tiles_n = ceil_div(N, T::BN);
@@ -220,7 +214,7 @@ int launch_dma(int layout, GemmParams& p, hipStream_t s) {
     p.k_per_split = ksteps_per * BK;
     splits = ceil_div(K, p.k_per_split);
     dim3 grid(p.tiles_m * p.tiles_n, splits), block(T::NT);
-    if (T::NW == 8 && stagger_on()) {
+    if (T::NW == 8 && stagger) {
         switch (layout) {
             case 0: hipLaunchKernelGGL((gemm_dma_kernel<T, false, false, T::NW == 8>), grid, block, 0, s, p); break;
             case 1: hipLaunchKernelGGL((gemm_dma_kernel<T, false, true, T::NW == 8>), grid, block, 0, s, p); break;
@@ -242,12 +236,8 @@ extern "C" int mh_gemm_grouped_tn(const MhGroupedGemm* table_device, int n_probl
                                   int queue_len, void* stream) {
     MH_CHECK_ARG(table_device && tile_queues && n_problems > 0 && n_problems < 65536 && queue_len > 0,
                  "mh_gemm_grouped_tn: bad arguments");
-    if (stagger_on())
-        hipLaunchKernelGGL((gemm_dma_grouped_tn_kernel<T256, true>), dim3(8 * queue_len), dim3(T256::NT), 0, (hipStream_t)stream,
-                           table_device, n_problems, tile_queues, queue_len);
-    else
-        hipLaunchKernelGGL((gemm_dma_grouped_tn_kernel<T256, false>), dim3(8 * queue_len), dim3(T256::NT), 0, (hipStream_t)stream,
-                           table_device, n_problems, tile_queues, queue_len);
+    hipLaunchKernelGGL((gemm_dma_grouped_tn_kernel<T256, true>), dim3(8 * queue_len), dim3(T256::NT), 0, (hipStream_t)stream,
+                       table_device, n_problems, tile_queues, queue_len);
     MH_LAUNCH_CHECK();
     return 0;
 }
@@ -275,6 +265,7 @@ int gemm_dma_dispatch(int tile, int layout, int M, int N, int K, const void* A, 
         case MH_TILE_DMA_128x256: rc = launch_dma<T128x256>(layout, p, s); break;
         case MH_TILE_DMA_128: rc = launch_dma<T128>(layout, p, s); break;
         case MH_TILE_DMA_128x4: rc = launch_dma<T128q>(layout, p, s); break;
+        case MH_TILE_DMA_256_LOCKSTEP: rc = launch_dma<T256>(layout, p, s, false); break;
         default: return -2;
     }
     if (rc) return rc;

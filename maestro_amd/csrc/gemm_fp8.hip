@@ -15,8 +15,6 @@
 //   operand map (checked with exact integer data, tests/test_fp8_gpu.py): lane l holds row (l & 15), K block (l >> 4) of 32
 //         consecutive bytes; C / D as every 16 x 16 MFMA: column l & 15, rows 4 (l >> 4) + r.
 #include "gemm_common.hpp"
-#include <stdlib.h>
-#include <string.h>
 
 namespace {
 
@@ -208,11 +206,12 @@ extern "C" int mh_gemm_fp8(int M, int N, int K, const void* A8, int lda, int a_f
     // beside it) unless the problem is long in K and fills the chip with 256 x 256 tiles for several rounds -- measured
     // (scripts/bench_fp8_gemm.py): 128^2 is as fast or faster on every shape of the C5 / C3 steps (e.g. 8192 x 768 x 3072:
     // 1403 vs 855 TFLOP/s; 32768 x 3072 x 512: 1090 vs 1061), 256^2 wins at 16384 x 4096 x 4096 (2140 vs 1796).
-    // MH_FP8_TILE=128|256 forces one (experiments).
+    // MH_GEMM_FP8_TILE_* bits in `flags` force one (experiments, tests; the library reads no environment).
     const long tiles256 = (long)ceil_div(M, 256) * ceil_div(N, 256), tiles128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
-    const char* force = getenv("MH_FP8_TILE");       // "256", "128" (two-stage ring), "128d" (four-stage ring)
-    const bool big = force ? force[0] == '2' : (tiles256 >= 768 && K >= 2048);
-    const bool deep = force ? strcmp(force, "128d") == 0 : (tiles128 > 128 && tiles128 <= 256 && K >= 2048);   // (256 CUs: at most one tile per CU)
+    const int force = flags & (MH_GEMM_FP8_TILE_256 | MH_GEMM_FP8_TILE_128 | MH_GEMM_FP8_TILE_128D);
+    p.flags = flags & ~force;
+    const bool big = force ? (force & MH_GEMM_FP8_TILE_256) != 0 : (tiles256 >= 768 && K >= 2048);
+    const bool deep = force ? (force & MH_GEMM_FP8_TILE_128D) != 0 : (tiles128 > 128 && tiles128 <= 256 && K >= 2048);   // (256 CUs: at most one tile per CU)
     if (big) launch_fp8<T8_256>(p, a_format, (hipStream_t)stream);
     else if (deep) launch_fp8<T8_128D>(p, a_format, (hipStream_t)stream);
     else launch_fp8<T8_128>(p, a_format, (hipStream_t)stream);

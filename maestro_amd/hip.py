@@ -60,11 +60,13 @@ _I, _F, _L = ctypes.c_int, ctypes.c_float, ctypes.c_long
 
 # ---- GEMM: kernel / tile choice (include/maestro_hip.h MH_TILE_*)
 TILE_AUTO, TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128, TILE_DMA_128x4 = -1, 0, 1, 2, 3, 4, 5
+TILE_DMA_256_LOCKSTEP = 6   # MH_TILE_DMA_256 without the wave-group stagger (A/B experiments)
 TILES = (TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128, TILE_DMA_128x4)
 _LAYOUT_NAME = {0: "NT", 1: "NN", 2: "TN"}
 _TILE_NAME = {TILE_REG_128: "gemm_kernel<{}>", TILE_DMA_256: "gemm_dma_kernel<256x256,{}>",
               TILE_DMA_256x128: "gemm_dma_kernel<256x128,{}>", TILE_DMA_128x256: "gemm_dma_kernel<128x256,{}>",
-              TILE_DMA_128: "gemm_dma_kernel<128x128,{}>", TILE_DMA_128x4: "gemm_dma_kernel<128x128q,{}>"}
+              TILE_DMA_128: "gemm_dma_kernel<128x128,{}>", TILE_DMA_128x4: "gemm_dma_kernel<128x128q,{}>",
+              TILE_DMA_256_LOCKSTEP: "gemm_dma_kernel<256x256,{}>"}
 _tile_choice: dict = {}     # (layout, M, N, K, flags) -> fastest tile, filled while tuning is on
 _tuning = False
 
@@ -112,9 +114,18 @@ def _pick_tile(layout, M, N, K, flags, args) -> int:  # noqa: N803
     key = (layout, M, N, K, tflags)
     tile = _tile_choice.get(key)
     if tile is None:
+        # Experiment switches are resolved HERE, on the host side: the C library reads no environment (its header promises no
+        # process-global state).  MH_GEMM_TILE=<id> forces one tile; MH_GEMM_DMA=0 keeps everything on the register-staged
+        # kernel, =1 sends every eligible problem to the 256x256 LDS-DMA tile; MH_DMA_STAGGER=0 picks its lockstep form.
         forced = os.environ.get("MH_GEMM_TILE")
         if forced is not None:
             return int(forced)
+        dma = os.environ.get("MH_GEMM_DMA", "")[:1]
+        if dma == "0":
+            return TILE_REG_128
+        lockstep = os.environ.get("MH_DMA_STAGGER", "")[:1] == "0"
+        if (dma == "1" and layout != GEMM_TN and not (flags & ATOMIC)) or (lockstep and _uses_dma(layout, M, N, K, flags)):
+            return TILE_DMA_256_LOCKSTEP if lockstep else TILE_DMA_256
         if _tuning and not (flags & ATOMIC):   # accumulating outputs cannot be re-run for timing: the library's rule decides
             targs = list(args)
             targs[10], targs[17] = tflags, None
@@ -142,8 +153,8 @@ def gemm(layout: int, M: int, N: int, K: int, A, lda: int, B, ldb: int, C, ldc: 
         ev = _timer.record(_TILE_NAME[named].format(_LAYOUT_NAME[layout]), 2.0 * M * N * K, (M, N, K))
         ev[0].record()
     rc = _gemm_tile(tile, *args)
-    if rc == -2 and not explicit:      # e.g. MH_GEMM_TILE forced a DMA tile onto a problem with a K tail
-        rc = _gemm_tile(TILE_AUTO, *args)
+    if rc == -2 and not explicit:      # e.g. MH_GEMM_TILE / MH_GEMM_DMA=1 forced a DMA tile onto a problem with a K tail
+        rc = _gemm_tile(TILE_REG_128 if os.environ.get("MH_GEMM_DMA", "")[:1] == "1" else TILE_AUTO, *args)
     if rc == -2:
         raise HipExtensionError(f"mh_gemm_bf16_tile: problem ({M}, {N}, {K}) does not qualify for tile {tile}")
     _check(rc, "mh_gemm_bf16_tile")
@@ -495,11 +506,7 @@ _timer: KernelTimer | None = None
 
 
 def _uses_dma(layout, M, N, K, flags) -> bool:
-    """Mirror of prefer_dma() in csrc/gemm.hip (only used to label kernel timings)."""
-    import os
-    e = os.environ.get("MH_GEMM_DMA", "")
-    if e[:1] == "0":
-        return False
+    """Mirror of prefer_dma() in csrc/gemm.hip (labels kernel timings; decides where MH_DMA_STAGGER=0 applies)."""
     if layout == GEMM_TN or (flags & ATOMIC) or K % 32 or K < 256:
         return False
     tiles = -(-M // 256) * -(-N // 256)
@@ -766,6 +773,9 @@ FP8_MAX = {FP8_E4M3: 448.0, FP8_E5M2: 57344.0}
 QCHUNK = 4096   # elements per work item of mh_quant_batched (csrc/quant.hip)
 
 
+_FP8_TILE_HINT = {"256": 2048, "128": 4096, "128d": 8192}   # MH_GEMM_FP8_TILE_* (include/maestro_hip.h)
+
+
 def gemm_fp8(M, N, K, A8, lda, B8, ldb, C, ldc, descale_a, descale_b, flags=0, a_format=FP8_E4M3, bias=None, res=None, ldr=0,  # noqa: N803
              aux_in=None, aux_out=None, ldaux=0, colsum=None, c8=None, ldc8=0, c8_scale=None, c8_amax=None) -> None:
     """``C = descale_a * descale_b * A8 @ B8^T`` (+ epilogue): A8 ``[M, K]`` / B8 ``[N, K]`` uint8 tensors holding OCP fp8."""
@@ -773,6 +783,7 @@ def gemm_fp8(M, N, K, A8, lda, B8, ldb, C, ldc, descale_a, descale_b, flags=0, a
     if _timer is not None:
         ev = _timer.record("gemm_fp8_kernel", 2.0 * M * N * K, (M, N, K))
         ev[0].record()
+    flags |= _FP8_TILE_HINT.get(os.environ.get("MH_FP8_TILE", ""), 0)      # (experiments / tests; the library reads no environment)
     _check(lib().mh_gemm_fp8(_I(M), _I(N), _I(K), ptr(A8), _I(lda), _I(a_format), ptr(B8), _I(ldb), ptr(C), _I(ldc), _I(flags),
                              ptr(descale_a), ptr(descale_b), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux),
                              ptr(colsum), ptr(c8), _I(ldc8), ptr(c8_scale), ptr(c8_amax), stream()), "mh_gemm_fp8")

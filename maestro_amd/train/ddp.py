@@ -32,8 +32,34 @@ def broadcast_parameters(engine, group=None, src: int = 0) -> None:
     if not _active(group) or dist.get_world_size(group) == 1:
         return
     dist.broadcast(engine.store.flat, src, group=group)
+    resync_engine(engine)
+
+
+def resync_engine(engine) -> None:
+    """The fp32 masters were replaced wholesale behind the engine's back (a broadcast, a checkpoint load): rebuild every
+    derived copy.  In fp8 mode the e4m3 scales must come from the NEW weights' absmax -- the one-pass delayed-scaling
+    refresh would cast rank ``src``'s weights with scales derived from the local ones and saturate silently at +-448."""
     engine.store.refresh_half(force=True)
+    fp8 = getattr(engine, "fp8", None)
+    if fp8 is not None:
+        fp8._w_ready = False
     engine._pack_conv_weights()
+
+
+def broadcast_module(module: torch.nn.Module, group=None, src: int = 0) -> None:
+    """Rank ``src``'s parameters and buffers into every rank's ``module`` (what DistributedDataParallel does at wrap time).
+    Works before any engine exists; with the NCCL (= RCCL) backend CPU-resident tensors are staged through the GPU."""
+    if not _active(group) or dist.get_world_size(group) == 1:
+        return
+    needs_gpu = dist.get_backend(group) == "nccl"
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            if needs_gpu and not t.is_cuda:
+                st = t.detach().to(torch.device("cuda", torch.cuda.current_device()))
+                dist.broadcast(st, src, group=group)
+                t.copy_(st)
+            else:
+                dist.broadcast(t.detach(), src, group=group)
 
 
 class GradSync:
@@ -150,21 +176,43 @@ class EngineDDPCallback:
 
     def __init__(self, bucket_mb: int = 64, group=None) -> None:
         self.bucket_bytes, self.group, self._sync, self._engine = bucket_mb << 20, group, None, None
+        self._module_synced = False
+
+    def _sync_module(self, pl_module) -> None:
+        """Rank 0's weights BEFORE the first forward, as Lightning's DDP wrap gives them (``maestro/conf/trainer.py:9-14``):
+        the engine is only built by the first ``training_step``, so the module itself is broadcast; an engine built from it
+        afterwards starts from the synchronised parameters (its flat buffer adopts the module's values)."""
+        if self._module_synced or not _active(self.group) or not isinstance(pl_module, torch.nn.Module):
+            return
+        broadcast_module(pl_module, self.group)
+        self._module_synced = True
+        engine = self._engine_of(pl_module)
+        if engine is not None:          # built before the fit started: its parameters are views of the flat buffer
+            resync_engine(engine)
 
     def _attach(self, engine) -> None:
         if engine is self._engine:
             return
         self._engine = engine
-        broadcast_parameters(engine, self.group)
+        if not self._module_synced:     # direct use without the fit hooks: fall back to the flat-buffer broadcast
+            broadcast_parameters(engine, self.group)
+            self._module_synced = True
         self._sync = GradSync(engine.store.grad_all, self.bucket_bytes, self.group, always_ready_from=engine.store.total)
 
     def _engine_of(self, pl_module):
         return getattr(pl_module.model, "_engine", None) or getattr(pl_module.model, "_sup_engine", None)
 
+    def on_fit_start(self, trainer, pl_module) -> None:  # noqa: ARG002
+        self._sync_module(pl_module)
+
+    def on_train_start(self, trainer, pl_module) -> None:  # noqa: ARG002
+        self._sync_module(pl_module)
+
     def on_train_batch_start(self, trainer, pl_module, batch, batch_idx) -> None:  # noqa: ARG002
+        self._sync_module(pl_module)   # (no-op after on_fit_start; covers trainers that only call the batch hooks)
         engine = self._engine_of(pl_module)
         if engine is not None and _active(self.group):
-            self._attach(engine)       # (the engine exists from the first training_step on: weights are synchronised at step 1)
+            self._attach(engine)
 
     def on_after_backward(self, trainer, pl_module) -> None:  # noqa: ARG002
         """The exchange is NOT overlapped with the backward here: the autograd bridge may still rescale / accumulate the

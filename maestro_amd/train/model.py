@@ -65,12 +65,14 @@ _RenamingPickle = types.SimpleNamespace(Unpickler=_RenamingUnpickler, load=lambd
 def _reference_class_paths():
     """While a checkpoint is written: make ``maestro.conf.mask.MaskConfig`` resolvable for pickle (it only stores the
     path + the field dict).  When the real reference is importable nothing is faked."""
-    try:
-        import maestro.conf.mask  # noqa: F401
+    try:                               # (only the import is guarded: an exception thrown into the generator from the
+        import maestro.conf.mask  # noqa: F401   with-body -- e.g. torch.save failing -- must propagate, not yield twice)
+        real = True
+    except Exception:  # noqa: BLE001
+        real = False
+    if real:
         yield
         return
-    except Exception:  # noqa: BLE001
-        pass
     from maestro_amd.conf import MaskConfig
     fake = {}
     for name in ("maestro", "maestro.conf", "maestro.conf.mask"):
@@ -124,7 +126,9 @@ class MeanMetric(nn.Module):
         total, count = self.total, float(self.count)
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dev = self._sum.device if (self._sum is not None and dist.get_backend() == "nccl") else "cpu"
+            # NCCL (= RCCL) groups only reduce device tensors: always this rank's current GPU, also for a rank that saw
+            # Python floats only (or nothing) -- a CPU tensor there would raise, or hang the ranks that did see tensors
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
             t = torch.tensor([total, count], dtype=torch.float64, device=dev)
             dist.all_reduce(t)
             total, count = float(t[0]), float(t[1])

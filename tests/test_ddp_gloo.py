@@ -114,6 +114,10 @@ class _FakeEngine:
         self.packed += 1
 
 
+class _FakeFp8:
+    _w_ready = True
+
+
 def _slot_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -151,6 +155,25 @@ def _slot_worker(rank, world, port, out):
     cb.on_train_batch_start(None, mod, None, 0)
     cb.on_after_backward(None, mod)
     cb_ok = bool((st.grad == 1.5).all()) and bool((st.flat == 5.0).all())
+    # the fit hooks: rank 0's weights reach every rank BEFORE the first forward (no engine exists yet), as with Lightning's
+    # DDP wrap; an engine that already exists is resynchronised, its fp8 scales rebuilt from the new weights
+    class Mod(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.full((7,), float(rank + 3)))
+            self.register_buffer("steps", torch.tensor([rank + 11]))
+            self.model = SimpleNamespace(_engine=None, _sup_engine=None)
+    cb2, mod2 = EngineDDPCallback(bucket_mb=1), Mod()
+    cb2.on_fit_start(None, mod2)
+    early_ok = bool((mod2.w == 3.0).all()) and int(mod2.steps) == 11 and cb2._engine is None
+    eng2 = _FakeEngine(n, rank)
+    eng2.fp8 = _FakeFp8()
+    cb3, mod3 = EngineDDPCallback(bucket_mb=1), Mod()
+    mod3.model._engine = eng2
+    cb3.on_train_batch_start(None, mod3, None, 0)
+    early_ok = early_ok and bool((mod3.w == 3.0).all()) and eng2.store.refreshed == 1 and eng2.packed == 1 \
+        and eng2.fp8._w_ready is False and cb3._sync is not None
+    cb_ok = cb_ok and early_ok
     met = MeanMetric()
     met.update(torch.tensor(float(rank + 1)))
     met.update(3.0 * (rank + 1))
