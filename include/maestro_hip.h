@@ -65,11 +65,14 @@ int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const 
  *   MH_TILE_DMA_256x128 / MH_TILE_DMA_128x256   4 waves, 3-stage ring;   MH_TILE_DMA_128   128x128, 2 waves, 4-stage ring
  *   MH_TILE_DMA_128x4    128x128, four 64x64 waves, 4-stage ring (the register-staged kernel's geometry, DMA-fed)
  *   MH_TILE_DMA_256_LOCKSTEP   MH_TILE_DMA_256 without the wave-group stagger (A/B experiments; bit-identical results)
+ *   MH_TILE_PP_128       persistent workgroups over 128x128x64 tiles with a second accumulator set: the epilogue of tile t runs
+ *                        inside the main loop of tile t + 1 (gemm_pp.hip); NT / NN, K %% 64 == 0, K >= 512, N %% 128 == 0, and
+ *                        flags one of: 0 | BIAS+GELU+AUX_DGELU+AUX_U8 | MULAUX+AUX_U8+COLSUM | OUT_F32+BIAS+RESIDUAL
  * The DMA tiles return -2 (nothing launched, error string untouched) when the problem does not qualify (K %% 32 != 0 with
  * a K-minor operand, operands beyond the 2 GiB buffer-descriptor range): pick another tile.  The host side times the
  * eligible tiles once per distinct (layout, M, N, K, flags) and remembers the fastest (maestro_amd/hip.py). */
 enum { MH_TILE_AUTO = -1, MH_TILE_REG_128 = 0, MH_TILE_DMA_256 = 1, MH_TILE_DMA_256x128 = 2, MH_TILE_DMA_128x256 = 3,
-       MH_TILE_DMA_128 = 4, MH_TILE_DMA_128x4 = 5, MH_TILE_DMA_256_LOCKSTEP = 6 };
+       MH_TILE_DMA_128 = 4, MH_TILE_DMA_128x4 = 5, MH_TILE_DMA_256_LOCKSTEP = 6, MH_TILE_PP_128 = 7 };
 int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                       int ldaux, float* colsum, void* stream);

@@ -10,106 +10,9 @@
 // The MFMA is issued with swapped operands (D' = B_tile * A_tile^T) so every lane owns 4 CONSECUTIVE output
 // columns of one row: bias/residual/aux are read and C is written with 8/16-byte vectors.
 // Split-K + fp32 atomics (LDS-transposed so each wave instruction adds 256 contiguous bytes) serve the wgrad.
-#include "gemm_common.hpp"
+#include "gemm_reg.hpp"
 
 namespace {
-
-constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
-constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile, 16 KiB
-
-typedef __attribute__((address_space(3))) unsigned char lds_u8;
-
-__device__ __forceinline__ int kmajor_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
-
-// ---- global -> registers (4 x 16 B per thread per operand tile)
-template <bool KMAJOR>
-__device__ __forceinline__ void load_tile(const bf16_t* __restrict__ P, int ld, int row0, int nrows, int k0, int kend,
-                                          u32x4 (&v)[4]) {
-    const int t = threadIdx.x;
-    if constexpr (!KMAJOR) {  // memory: P[row * ld + k]
-        const int c = t & 7, r = t >> 3;
-        const int gk = k0 + c * 8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int grow = row0 + r + 32 * i;
-            u32x4 z = {0, 0, 0, 0};
-            if (grow < nrows && gk < kend) z = *reinterpret_cast<const u32x4*>(P + (size_t)grow * ld + gk);
-            v[i] = z;
-        }
-    } else {  // memory: P[k * ld + col]
-        const int c = t & 15, kk = t >> 4;
-        const int gcol = row0 + c * 8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gk = k0 + kk + 16 * i;
-            u32x4 z = {0, 0, 0, 0};
-            if (gk < kend && gcol < nrows) z = *reinterpret_cast<const u32x4*>(P + (size_t)gk * ld + gcol);
-            v[i] = z;
-        }
-    }
-}
-
-// ---- fast path: buffer loads.  The 128-bit resource descriptor carries the exact byte extent of the operand, so rows
-// beyond M / N (K-minor) or beyond K (K-major) read as zero in hardware; per-thread byte offsets are loop-invariant
-// 32-bit VGPRs and the K advance is ONE scalar offset -> no per-step predication, no 64-bit vector address math.
-template <bool KMAJOR>
-__device__ __forceinline__ void tile_offsets(int ld, int row0, int (&voff)[4]) {
-    const int t = threadIdx.x;
-    if constexpr (!KMAJOR) {
-        const int c = t & 7, r = t >> 3;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) voff[i] = ((row0 + r + 32 * i) * ld + c * 8) * 2;
-    } else {
-        const int c = t & 15, kk = t >> 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) voff[i] = ((kk + 16 * i) * ld + row0 + c * 8) * 2;
-    }
-}
-__device__ __forceinline__ void load_tile_fast(__amdgpu_buffer_rsrc_t rsrc, const int (&voff)[4], int soff, u32x4 (&v)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], soff, 0);
-}
-
-// ---- registers -> swizzled LDS tile
-template <bool KMAJOR>
-__device__ __forceinline__ void store_tile(unsigned char* tile, const u32x4 (&v)[4]) {
-    const int t = threadIdx.x;
-    if constexpr (!KMAJOR) {
-        const int c = t & 7, r = t >> 3;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = r + 32 * i;
-            *reinterpret_cast<u32x4*>(tile + row * 128 + ((c ^ (row & 7)) << 4)) = v[i];
-        }
-    } else {
-        const int c = t & 15, kk = t >> 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = kk + 16 * i;
-            *reinterpret_cast<u32x4*>(tile + k * 256 + ((((c >> 1) ^ kmajor_f(k)) << 5) | ((c & 1) << 4))) = v[i];
-        }
-    }
-}
-
-// ---- LDS -> MFMA fragment: 8 bf16 along k for row/col (rc0 + lane&15), k = 32*s + 8*(lane>>4) + j
-template <bool KMAJOR>
-__device__ __forceinline__ bf16x8 read_frag(const unsigned char* tile, int rc0, int s) {
-    const int l = threadIdx.x & 63;
-    if constexpr (!KMAJOR) {
-        const int row = rc0 + (l & 15), ch = 4 * s + (l >> 4);
-        return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((ch ^ (row & 7)) << 4));
-    } else {
-        const int g = l >> 4, qrow = (l & 15) >> 2, p = l & 3, q = rc0 >> 4;
-        const int k_lo = 32 * s + 8 * g + qrow, k_hi = k_lo + 4;
-        const lds_u8* base = (const lds_u8*)tile;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(base + k_lo * 256 + (((q ^ kmajor_f(k_lo)) << 5) + p * 8)));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(base + k_hi * 256 + (((q ^ kmajor_f(k_hi)) << 5) + p * 8)));
-        s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8, r);
-    }
-}
 
 // Measured alternatives that lost on MI355X (kept out of the code): a second register set / 2-step-deep prefetch (halves
 // occupancy, ~2x slower); one LDS buffer + two barriers per K step at 4 workgroups per CU (NN/TN spill under the
@@ -307,7 +210,7 @@ static bool prefer_dma(int layout, int M, int N, int K, int flags) {
 extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                                  void* C, int ldc, int flags, const float* bias, const float* res, int ldr,
                                  const void* aux_in, void* aux_out, int ldaux, float* colsum, void* stream) {
-    MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_DMA_256_LOCKSTEP, "mh_gemm_bf16: tile %d", tile);
+    MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_PP_128, "mh_gemm_bf16: tile %d", tile);
     MH_CHECK_ARG(layout >= 0 && layout <= 2, "mh_gemm_bf16: layout %d", layout);
     MH_CHECK_ARG(M > 0 && N > 0 && K > 0, "mh_gemm_bf16: empty problem %d %d %d", M, N, K);
     MH_CHECK_ARG(A && B && C, "mh_gemm_bf16: null operand");
@@ -336,9 +239,21 @@ extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, cons
     MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || !(flags & ~(MH_GEMM_ATOMIC | MH_GEMM_OUT_F32)),
                  "mh_gemm_bf16: atomic accumulate excludes other epilogues");
 
+    if (tile == MH_TILE_PP_128)
+        return gemm_pp_dispatch(layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, stream);
     if (tile > MH_TILE_REG_128)   // explicit DMA tile: -2 when not eligible (the caller picks another tile)
         return gemm_dma_dispatch(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, stream);
-    if (tile == MH_TILE_AUTO && prefer_dma(layout, M, N, K, flags)) {
+    // Persistent 128x128 tile with the epilogue inside the next tile's main loop (gemm_pp.hip), scripts/bench_pp.py on the C3
+    // step's shapes with their real epilogues: +6...12 % on the plain bf16 NT outputs (qkv), +3...10 % on fp32 + residual
+    // (out-proj, fc2) and on the plain NN dgrads, +3 % on fc1; it LOSES 8-20 % on the fc2 dgrad (MULAUX + column sums: 256
+    // VGPRs, spills) -> never picked there.  Against the 256x256 LDS-DMA tile (M = 32768) it wins only the short-K NT problems
+    // without the GELU (qkv 64.6 vs 68.1 us, out-proj 38.9 vs 43.4 us).
+    const bool dma = tile == MH_TILE_AUTO && prefer_dma(layout, M, N, K, flags);
+    if (tile == MH_TILE_AUTO && !(flags & MH_GEMM_MULAUX) && (!dma || (layout == 0 && K < 1024 && !(flags & MH_GEMM_GELU)))) {
+        const int rc = gemm_pp_dispatch(layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, stream);
+        if (rc != -2) return rc;   // -2: not eligible -> the kernels below
+    }
+    if (dma) {
         const int rc = gemm_dma_dispatch(MH_TILE_DMA_256, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in,
                                          aux_out, ldaux, colsum, stream);
         if (rc != -2) return rc;   // -2: not eligible -> general kernel below

@@ -61,12 +61,13 @@ _I, _F, _L = ctypes.c_int, ctypes.c_float, ctypes.c_long
 # ---- GEMM: kernel / tile choice (include/maestro_hip.h MH_TILE_*)
 TILE_AUTO, TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128, TILE_DMA_128x4 = -1, 0, 1, 2, 3, 4, 5
 TILE_DMA_256_LOCKSTEP = 6   # MH_TILE_DMA_256 without the wave-group stagger (A/B experiments)
+TILE_PP_128 = 7             # persistent 128x128 tile, epilogue of tile t inside the main loop of tile t + 1 (gemm_pp.hip)
 TILES = (TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128, TILE_DMA_128x4)
 _LAYOUT_NAME = {0: "NT", 1: "NN", 2: "TN"}
 _TILE_NAME = {TILE_REG_128: "gemm_kernel<{}>", TILE_DMA_256: "gemm_dma_kernel<256x256,{}>",
               TILE_DMA_256x128: "gemm_dma_kernel<256x128,{}>", TILE_DMA_128x256: "gemm_dma_kernel<128x256,{}>",
               TILE_DMA_128: "gemm_dma_kernel<128x128,{}>", TILE_DMA_128x4: "gemm_dma_kernel<128x128q,{}>",
-              TILE_DMA_256_LOCKSTEP: "gemm_dma_kernel<256x256,{}>"}
+              TILE_DMA_256_LOCKSTEP: "gemm_dma_kernel<256x256,{}>", TILE_PP_128: "gemm_pp_kernel<{}>"}
 _tile_choice: dict = {}     # (layout, M, N, K, flags) -> fastest tile, filled while tuning is on
 _tuning = False
 
@@ -121,6 +122,8 @@ def _pick_tile(layout, M, N, K, flags, args) -> int:  # noqa: N803
         if forced is not None:
             return int(forced)
         dma = os.environ.get("MH_GEMM_DMA", "")[:1]
+        if os.environ.get("MH_GEMM_PP", "")[:1] == "0" and dma == "":   # A/B: the round-2 rule (no persistent ping-pong tile)
+            return TILE_DMA_256 if _uses_dma(layout, M, N, K, flags) else TILE_REG_128
         if dma == "0":
             return TILE_REG_128
         lockstep = os.environ.get("MH_DMA_STAGGER", "")[:1] == "0"
@@ -135,7 +138,19 @@ def _pick_tile(layout, M, N, K, flags, args) -> int:  # noqa: N803
     return tile
 
 
+def _uses_pp(layout, M, N, K, flags) -> bool:  # noqa: N803
+    """Mirror of the MH_TILE_AUTO rule in csrc/gemm.hip + gemm_pp_dispatch's eligibility (labels kernel timings only)."""
+    if os.environ.get("MH_GEMM_PP", "")[:1] == "0":
+        return False
+    served = flags in (0, BIAS | GELU | AUX_DGELU | AUX_U8, OUT_F32 | BIAS | RESIDUAL)
+    if not served or layout == GEMM_TN or K % 64 or K < 512 or N % 128:
+        return False
+    return not _uses_dma(layout, M, N, K, flags) or (layout == GEMM_NT and K < 1024 and not (flags & GELU))
+
+
 def _auto_tile_name(layout, M, N, K, flags) -> int:  # noqa: N803
+    if _uses_pp(layout, M, N, K, flags):
+        return TILE_PP_128
     return TILE_DMA_256 if _uses_dma(layout, M, N, K, flags) else TILE_REG_128
 
 

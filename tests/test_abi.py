@@ -68,3 +68,10 @@ def test_product_never_imports_the_oracle():
     for py in (ROOT / "maestro_amd").rglob("*.py"):
         text = py.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f"{py} imports the oracle"
+
+
+def test_library_reads_no_environment():
+    """include/maestro_hip.h promises "no global mutable state": every tile / ring choice is an argument, the experiment
+    switches (MH_GEMM_TILE, MH_GEMM_DMA, MH_DMA_STAGGER, MH_FP8_TILE) are parsed on the host side (maestro_amd/hip.py)."""
+    for src in list((ROOT / "maestro_amd" / "csrc").glob("*.hip")) + list((ROOT / "maestro_amd" / "csrc").glob("*.hpp")):
+        assert "getenv" not in src.read_text(), f"{src.name} reads the environment"

@@ -151,3 +151,83 @@ def test_saved_gelu_derivative_as_bytes(M, N, K):
     assert (cs8 - cs16).abs().max() <= 2e-2 * cs16.abs().max()
     with pytest.raises(hip.HipExtensionError):
         hip.gemm(hip.GEMM_NT, M, N, K, A, K, B, K, act8, N, hip.BIAS | hip.GELU | hip.AUX_U8, bias=bias, aux_out=aux8, ldaux=N)
+
+
+# ---- MH_TILE_PP_128 (gemm_pp.hip): persistent workgroups, the epilogue of tile t inside the main loop of tile t + 1
+_PP_SHAPES = [(5100, 2048, 512), (8192, 3072, 768), (3000, 1536, 640), (1000, 256, 512)]   # > 512 tiles, 3 tiles per workgroup,
+                                                                                          # a ragged run, one tile per workgroup
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("shape", _PP_SHAPES)
+def test_gemm_pp_exact_integers(layout, shape):
+    from maestro_amd import hip
+    dev = _dev()
+    M, N, K = shape
+    A, B, want = _operands(layout, M, N, K, dev, integer=True)
+    Cb = torch.full((M + 3, N), 7.0, device=dev, dtype=torch.bfloat16)     # three guard rows behind the output
+    hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], Cb, N, 0, tile=hip.TILE_PP_128)
+    torch.cuda.synchronize()
+    assert torch.equal(Cb[:M], want.bfloat16()), f"max diff {(Cb[:M].float() - want).abs().max().item()}"
+    assert bool((Cb[M:] == 7.0).all()), "rows beyond M were written"
+    g = torch.Generator().manual_seed(5)
+    bias = torch.randint(-4, 5, (N,), generator=g).float().to(dev)
+    res = torch.randint(-9, 10, (M, N), generator=g).float().to(dev)
+    C = torch.full((M + 3, N), 7.0, device=dev)
+    hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], C, N, hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=bias, res=res, ldr=N,
+             tile=hip.TILE_PP_128)
+    torch.cuda.synchronize()
+    assert torch.equal(C[:M], want + bias + res) and bool((C[M:] == 7.0).all())
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("shape", _PP_SHAPES[:3])
+def test_gemm_pp_epilogues_match_the_one_tile_kernel(layout, shape):
+    """Same fp32 sums (same MFMA order), same epilogue arithmetic -> the persistent kernel's outputs are compared bit for bit with
+    mh_gemm_bf16's register-staged kernel (column sums: other summation order, fp32 tolerance)."""
+    from maestro_amd import hip
+    dev = _dev()
+    M, N, K = shape
+    A, B, _ = _operands(layout, M, N, K, dev, integer=False)
+    g = torch.Generator().manual_seed(11)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    lda, ldb = A.shape[1], B.shape[1]
+
+    def run(tile, flags, out_dtype, **kw):
+        C = torch.zeros((M, N), device=dev, dtype=out_dtype)
+        hip.gemm(layout, M, N, K, A, lda, B, ldb, C, N, flags, tile=tile, **kw)
+        torch.cuda.synchronize()
+        return C
+
+    for flags, dt, kw in [(0, torch.bfloat16, {}),
+                          (hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, torch.float32, dict(bias=bias, res=res, ldr=N))]:
+        assert torch.equal(run(hip.TILE_PP_128, flags, dt, **kw), run(hip.TILE_REG_128, flags, dt, **kw)), flags
+    # fc1: bias + GELU, GELU' saved as bytes
+    fl = hip.BIAS | hip.GELU | hip.AUX_DGELU | hip.AUX_U8
+    aux = [torch.zeros((M, N), device=dev, dtype=torch.uint8) for _ in range(2)]
+    c_pp = run(hip.TILE_PP_128, fl, torch.bfloat16, bias=bias, aux_out=aux[0], ldaux=N)
+    c_ref = run(hip.TILE_REG_128, fl, torch.bfloat16, bias=bias, aux_out=aux[1], ldaux=N)
+    # (the two kernels contract the GELU arithmetic into FMAs differently: a few results land on the neighbouring bf16 / code)
+    ulp = (c_pp.view(torch.int16).int() - c_ref.view(torch.int16).int()).abs()
+    assert ulp.max().item() <= 1 and (ulp != 0).float().mean().item() < 2e-3, (ulp.max().item(), (ulp != 0).float().mean().item())
+    dcode = (aux[0].int() - aux[1].int()).abs()
+    assert dcode.max().item() <= 1 and (dcode != 0).float().mean().item() < 2e-3
+    # fc2 dgrad: multiply by the saved derivative + 64-row block column sums
+    fl = hip.MULAUX | hip.AUX_U8 | hip.COLSUM
+    cs = [torch.full(((M + 63) // 64, N), float("nan"), device=dev) for _ in range(2)]
+    c_pp = run(hip.TILE_PP_128, fl, torch.bfloat16, aux_in=aux[1], ldaux=N, colsum=cs[0])
+    c_ref = run(hip.TILE_REG_128, fl, torch.bfloat16, aux_in=aux[1], ldaux=N, colsum=cs[1])
+    ulp = (c_pp.view(torch.int16).int() - c_ref.view(torch.int16).int()).abs()
+    assert ulp.max().item() <= 1 and (ulp != 0).float().mean().item() < 2e-3
+    assert torch.isfinite(cs[0]).all() and (cs[0] - cs[1]).abs().max().item() <= 2e-5 * cs[1].abs().max().item() + 1e-6
+
+
+def test_gemm_pp_declines_what_it_does_not_serve():
+    from maestro_amd import hip
+    dev = _dev()
+    A = torch.zeros(256, 512, device=dev, dtype=torch.bfloat16)
+    C = torch.zeros(256, 256, device=dev, dtype=torch.bfloat16)
+    for args in [dict(K=448), dict(N=192), dict(flags=hip.BIAS)]:       # K < 512, N % 128, an epilogue it has no form for
+        K, N, flags = args.get("K", 512), args.get("N", 256), args.get("flags", 0)
+        with pytest.raises(hip.HipExtensionError):
+            hip.gemm(0, 256, N, K, A, 512, A, 512, C, 256, flags, bias=torch.zeros(256, device=dev), tile=hip.TILE_PP_128)
