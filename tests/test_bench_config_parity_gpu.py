@@ -1,0 +1,112 @@
+"""Parity AT THE BENCH CONFIGURATION: C3 (ViT-B, aerial 512x512x4 + Sentinel-2 16x10x10x10) at B = 32 tiles through
+``PretrainLoop``'s default plan -- hipGraph replay, group-parallel streams, the deferred grouped weight-gradient launch
+(2652 tiles), ``MH_TILE_AUTO`` dispatch (the persistent ping-pong tile, the 256x256 LDS-DMA NT / NN kernels on the M = 32768
+decoder problems) -- against ``oracle.mae.build_oracle`` with the same weights, inputs and injected host draws.
+
+The step compared is the THIRD one (step 1 runs eagerly, step 2 is captured, step 3 is the first replay), with a zero learning
+rate so that the weights of step 3 are the initial ones (AdamW with lr = 0 leaves every parameter bit-identical: p -= 0 * ...).
+The loop draws its masks itself (``MAEEngine.forward`` -> ``draw_masks`` on torch's global CPU generator, the reference's
+source: ``maestro/ssl/mae.py:178-264``); re-seeding the generator reproduces the same draws for the oracle.
+
+Reference semantics: ``maestro/ssl/mim.py:473-505`` (forward) + ``maestro/train/model.py:195-247`` (loss).  Tolerances: the
+full-width ones of tests/test_fullwidth_parity_gpu.py.  The oracle's forward + backward at B = 32 takes ~30-60 s of CPU.
+"""
+
+import pytest
+import torch
+
+import bench
+import maestro_amd.conf as conf
+from maestro_amd.ssl import mae as pmae
+from oracle import mae as om
+from oracle.gen_golden import init_weights
+
+pytestmark = pytest.mark.gpu
+LOSS_TOL, PIX_TOL, GRAD_TOL = 1e-3, 2e-2, 4.5e-2
+COMMON = dict(interpolate="nearest", fusion_mode="group", inter_depth=3, model="mae", num_levels=1)
+
+
+def _rel(a, b):
+    return ((a - b).double().norm() / b.double().norm().clamp(min=1e-12)).item()
+
+
+def test_c3_b32_replayed_step_matches_oracle(observed):
+    from maestro_amd import hip
+    from maestro_amd.train.trainer import PretrainLoop, synthetic_batch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    B = 32
+    w = bench.WORKLOADS["c3"]
+    ds = w["ds"]()
+    torch.set_float32_matmul_precision("highest")
+    oracle = om.build_oracle(ds, conf.MaskConfig(), model_size=w["size"], **COMMON)
+    init_weights(oracle, 103)
+    model = getattr(pmae, f"mae_{w['size']}")(datasets=ds, mask=conf.MaskConfig(), **COMMON)
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    batch = synthetic_batch(ds.dataset, B, "cpu", seed=3)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}          # resident inputs: same addresses every step (graph replay)
+
+    loop = PretrainLoop(model, B, dev, loss="l2_norm", base_lr=0.0, total_steps=10)
+    eng = loop.engine
+    flat0 = eng.store.flat.clone()
+    timer = hip.KernelTimer()
+    for step in range(3):
+        torch.manual_seed(500 + step)
+        if step == 2:
+            assert eng.use_graphs and len(eng._graphs) >= 2, "step 3 must be a hipGraph replay (the bench's plan)"
+        loss = loop.step(dbatch)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.store.flat, flat0), "lr = 0 must leave the parameters bit-identical"
+    grad_replayed = eng.store.grad.clone()                       # every parameter gradient of the replayed step
+    torch.manual_seed(502)
+    noise, struct = eng.draw_masks()                             # the draws of step 3, reproduced
+    pixels, masks = eng.reconstructions()
+    got_loss = float(loss.item())
+
+    # which kernels did the bench plan dispatch to?  (one eager pass with the timer on: same problems, same rule)
+    hip.set_kernel_timer(timer)
+    try:
+        torch.manual_seed(502)
+        eng.forward(dbatch)                                       # (segments run eagerly while the timer is on)
+        eng.zero_grad()
+        eng.backward()
+        torch.cuda.synchronize()
+    finally:
+        hip.set_kernel_timer(None)
+    kinds = set(timer.count)
+    for need in ("gemm_pp_kernel<NT>", "gemm_dma_kernel<256x256,NT>", "gemm_dma_kernel<256x256,NN>", "gemm_dma_grouped_tn_kernel"):
+        assert need in kinds, f"{need} is not on the B = 32 path (kernels seen: {sorted(kinds)})"
+
+    ob, orec, omsk, _ = oracle({k: v.clone() for k, v in batch.items()}, "pretrain", noise=noise,
+                               struct_masks={g: s[:, :, None] for g, s in struct.items()})
+    oloss = om.compute_loss_rec(ob, orec, omsk, oracle.out_grid_size, om.norm_bands_of(ds.dataset), "l2_norm")
+    oracle.zero_grad()
+    oloss.backward()
+
+    tag = "bench_config/c3_b32"
+    for m in orec:
+        assert torch.equal(masks[m].cpu(), omsk[m]), f"{m}: mask differs from the oracle"
+        e = _rel(pixels[m].cpu(), orec[m].detach())
+        observed(tag, f"pixels/{m}", e)
+        assert e < PIX_TOL, (m, e)
+    e = abs(got_loss - oloss.item()) / abs(oloss.item())
+    observed(tag, "loss", e)
+    assert e < LOSS_TOL, (got_loss, oloss.item())
+    ograds = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
+    gmax = max(g.abs().max().item() for g in ograds.values())
+    worst, checked = (0.0, None), 0
+    for k, p in model.named_parameters():
+        if k not in ograds:
+            continue
+        o = eng.store.offset[id(p)]
+        got, want = grad_replayed[o: o + p.numel()].view(p.shape).cpu(), ograds[k]
+        err, ref = (got - want).double().norm().item(), want.double().norm().item()
+        floor = 1e-5 * gmax * want.numel() ** 0.5
+        if ref > 10 * floor and err / ref > worst[0]:
+            worst = (err / ref, k)
+        assert err <= GRAD_TOL * ref + floor, f"{k}: grad rel err {err / max(ref, 1e-12):.3e} (|ref| = {ref:.3e})"
+        checked += 1
+    observed(tag, f"grad_worst/{worst[1]}", worst[0])
+    assert checked == len(ograds) and checked > 100
+    print(f"[c3, B = 32, replayed step] loss hip={got_loss:.6f} oracle={oloss.item():.6f}; worst gradient rel L2 {worst}")

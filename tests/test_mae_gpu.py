@@ -56,6 +56,19 @@ def _setup(name, golden_dir):
 @pytest.mark.parametrize("name", list(CASES))
 def test_engine_matches_oracle_and_reference(golden_dir, name, wgrad, observed):
     """``wgrad``: weight gradients in line with the dgrad chain (split-K atomics) / deferred into one grouped launch."""
+    _check_case(golden_dir, name, wgrad, observed, f"tiny/{name}/{wgrad}")
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_goldens_through_the_lds_dma_tiles(golden_dir, name, observed, monkeypatch):
+    """The same 11 reference goldens with every eligible NT / NN GEMM forced onto the 256 x 256 LDS-DMA tile
+    (``MH_GEMM_DMA=1``, resolved in maestro_amd/hip.py): the kernel the M = 32768 decoder problems of the bench
+    configuration run on, which the tiny shapes would never pick by themselves."""
+    monkeypatch.setenv("MH_GEMM_DMA", "1")
+    _check_case(golden_dir, name, "deferred", observed, f"tiny_dma/{name}")
+
+
+def _check_case(golden_dir, name, wgrad, observed, tag):
     dev, case, gold, ds, oracle, model, batch, noise, struct = _setup(name, golden_dir)
     eng = model.engine(case["B"], dev, loss="l2_norm")
     eng.wgrad_mode = wgrad
@@ -81,11 +94,11 @@ def test_engine_matches_oracle_and_reference(golden_dir, name, wgrad, observed):
         tok = token_masks(masks[m].cpu(), ds.dataset.inputs[m]).numpy()
         ref_tok = np.unpackbits(gold[f"mask_tok/{m}"], axis=2)[:, :, : tok.shape[2]].astype(bool)
         assert np.array_equal(tok, ref_tok), f"{m}: mask indices differ from the reference"
-        observed(f"tiny/{name}/{wgrad}", f"pixels/{m}", _rel(pixels[m].cpu(), orec[m].detach()))
+        observed(tag, f"pixels/{m}", _rel(pixels[m].cpu(), orec[m].detach()))
         assert _rel(pixels[m].cpu(), orec[m].detach()) < PIX_TOL, (m, _rel(pixels[m].cpu(), orec[m].detach()))
         if group_of[m] not in multi:  # reference value independent of its implementation-defined tie order
             assert _rel(pixels[m].cpu(), torch.from_numpy(gold[f"pixels_rec/{m}"])) < PIX_TOL
-    observed(f"tiny/{name}/{wgrad}", "loss", abs(loss.item() - oloss.item()) / abs(oloss.item()))
+    observed(tag, "loss", abs(loss.item() - oloss.item()) / abs(oloss.item()))
     assert abs(loss.item() - oloss.item()) < LOSS_TOL * abs(oloss.item()), (loss.item(), oloss.item())
     if not multi:
         assert abs(loss.item() - float(gold["loss_l2_norm"])) < LOSS_TOL * abs(float(gold["loss_l2_norm"]))
@@ -103,7 +116,7 @@ def test_engine_matches_oracle_and_reference(golden_dir, name, wgrad, observed):
         if err / max(ref, 1e-12) > worst[0]:
             worst = (err / max(ref, 1e-12), k)
         assert ok, f"{k}: grad rel err {err / max(ref, 1e-12):.3e} (|ref|={ref:.3e})"
-    observed(f"tiny/{name}/{wgrad}", f"grad_worst/{worst[1]}", worst[0])
+    observed(tag, f"grad_worst/{worst[1]}", worst[0])
     print(f"[{name}] loss hip={loss.item():.6f} oracle={oloss.item():.6f} worst grad rel err {worst}")
 
 
