@@ -72,7 +72,10 @@ int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const 
  * a K-minor operand, operands beyond the 2 GiB buffer-descriptor range): pick another tile.  The host side times the
  * eligible tiles once per distinct (layout, M, N, K, flags) and remembers the fastest (maestro_amd/hip.py). */
 enum { MH_TILE_AUTO = -1, MH_TILE_REG_128 = 0, MH_TILE_DMA_256 = 1, MH_TILE_DMA_256x128 = 2, MH_TILE_DMA_128x256 = 3,
-       MH_TILE_DMA_128 = 4, MH_TILE_DMA_128x4 = 5, MH_TILE_DMA_256_LOCKSTEP = 6, MH_TILE_PP_128 = 7 };
+       MH_TILE_DMA_128 = 4, MH_TILE_DMA_128x4 = 5, MH_TILE_DMA_256_LOCKSTEP = 6, MH_TILE_PP_128 = 7,
+       /* diagnostic builds of MH_TILE_PP_128 (NT only; outputs are NOT the GEMM's): main loop only / epilogue arithmetic without
+        * its stores / stores without the GELU arithmetic -- the ablation under profiles/ (scripts/bench_pp_ablate.py) */
+       MH_TILE_PP_128_DIAG1 = 8, MH_TILE_PP_128_DIAG2 = 9, MH_TILE_PP_128_DIAG3 = 10 };
 int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                       int ldaux, float* colsum, void* stream);

@@ -210,7 +210,7 @@ static bool prefer_dma(int layout, int M, int N, int K, int flags) {
 extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                                  void* C, int ldc, int flags, const float* bias, const float* res, int ldr,
                                  const void* aux_in, void* aux_out, int ldaux, float* colsum, void* stream) {
-    MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_PP_128, "mh_gemm_bf16: tile %d", tile);
+    MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_PP_128_DIAG3, "mh_gemm_bf16: tile %d", tile);
     MH_CHECK_ARG(layout >= 0 && layout <= 2, "mh_gemm_bf16: layout %d", layout);
     MH_CHECK_ARG(M > 0 && N > 0 && K > 0, "mh_gemm_bf16: empty problem %d %d %d", M, N, K);
     MH_CHECK_ARG(A && B && C, "mh_gemm_bf16: null operand");
@@ -239,8 +239,9 @@ extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, cons
     MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || !(flags & ~(MH_GEMM_ATOMIC | MH_GEMM_OUT_F32)),
                  "mh_gemm_bf16: atomic accumulate excludes other epilogues");
 
-    if (tile == MH_TILE_PP_128)
-        return gemm_pp_dispatch(layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, stream);
+    if (tile >= MH_TILE_PP_128)
+        return gemm_pp_dispatch(layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, stream,
+                                tile - MH_TILE_PP_128);
     if (tile > MH_TILE_REG_128)   // explicit DMA tile: -2 when not eligible (the caller picks another tile)
         return gemm_dma_dispatch(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, stream);
     // Persistent 128x128 tile with the epilogue inside the next tile's main loop (gemm_pp.hip), scripts/bench_pp.py on the C3

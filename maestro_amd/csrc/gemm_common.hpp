@@ -61,7 +61,7 @@ int gemm_dma_dispatch(int tile, int layout, int M, int N, int K, const void* A, 
 // gemm_pp.hip: the persistent 128x128 tile with a second accumulator set (tile = MH_TILE_PP_128); -2 = not eligible
 int gemm_pp_dispatch(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int flags,
                      const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out, int ldaux, float* colsum,
-                     void* stream);
+                     void* stream, int diag = 0);
 
 // MH_GEMM_AUX_U8: the saved GELU derivative as a byte code, value = code / 200 - 0.13 (range [-0.129, 1.129] -> 0.2 .. 251.8)
 __device__ __forceinline__ u32x2 pack_dgelu_u8x8(f32x4 lo, f32x4 hi) {

@@ -37,7 +37,10 @@ __device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
     a = r[0]; b = r[1];
 }
 
-template <bool B_KMAJOR, int EPI>
+// DIAG (diagnostic builds for the ablation in profiles/: what does the interleaved epilogue cost, and which part of it?):
+//   0 the kernel;  1 no epilogue at all (main loop only: nothing is written);  2 the epilogue's arithmetic without its
+//   global stores (results kept alive by an empty asm);  3 its stores without the GELU arithmetic (raw accumulators packed)
+template <bool B_KMAJOR, int EPI, int DIAG = 0>
 __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // A0 A1 B0 B1
     const int T = p.tiles_m * p.tiles_n, G = gridDim.x;
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
     // chunk c = 0..7: pair jp = c >> 2 (column blocks 2 jp, 2 jp + 1), row block i = c & 3
     auto epi_loads = [&](auto cc) {
         constexpr int c = decltype(cc)::value, jp = c >> 2, i = c & 3;
+        if constexpr (DIAG == 1) return;
         if constexpr (EPI == EPI_GELU || EPI == EPI_F32) {
             if constexpr (i == 0) {
                 bias_x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, e_bias + 128 * jp, 0, 0));
@@ -141,6 +145,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
     auto epi_math = [&](auto cc, const f32x4 (&src)[4][4]) {
         constexpr int c = decltype(cc)::value, jp = c >> 2, i = c & 3;
         f32x4 vx = src[2 * jp][i], vy = src[2 * jp + 1][i];
+        if constexpr (DIAG == 1) {   // keep the accumulators alive, do nothing with them
+            asm volatile("" ::"v"(vx), "v"(vy));
+            return;
+        }
         if constexpr (EPI == EPI_F32) {
             const int o = e_c + (16 * i * p.ldc + 32 * jp) * 4;
             vx = vx + (bias_x + __builtin_bit_cast(f32x4, ld_x));   // (the order of gemm_common.hpp's fp32 epilogue: same bits)
@@ -152,8 +160,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
             if constexpr (EPI == EPI_GELU) {
                 vx += bias_x; vy += bias_y;
                 f32x4 cx, dx, cy, dy;
-                gelu_cdf_pdf4(vx, cx, dx);
-                gelu_cdf_pdf4(vy, cy, dy);
+                if constexpr (DIAG == 3) { cx = vx; dx = vx; cy = vy; dy = vy; }
+                else { gelu_cdf_pdf4(vx, cx, dx); gelu_cdf_pdf4(vy, cy, dy); }
                 const f32x4 gx = vx * dx + cx, gy = vy * dy + cy;      // GELU' = CDF + x PDF
                 uint32_t bx = 0, by = 0;
 #pragma unroll
@@ -162,7 +170,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
                     by = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(gy[e], 200.f, 26.f), e, by);
                 }
                 swap16(bx, by);
-                __builtin_amdgcn_raw_buffer_store_b64((u32x2){bx, by}, raux, e_aux + 16 * i * p.ldaux + 32 * jp, 0, 0);
+                if constexpr (DIAG == 2) asm volatile("" ::"v"(bx), "v"(by));
+                else __builtin_amdgcn_raw_buffer_store_b64((u32x2){bx, by}, raux, e_aux + 16 * i * p.ldaux + 32 * jp, 0, 0);
                 vx *= cx; vy *= cy;
             }
             if constexpr (EPI == EPI_MULAUX) {
@@ -187,7 +196,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
             uint32_t y0 = pack_bf2(vy[0], vy[1]), y1 = pack_bf2(vy[2], vy[3]);
             swap16(x0, y0);
             swap16(x1, y1);
-            __builtin_amdgcn_raw_buffer_store_b128((u32x4){x0, x1, y0, y1}, rc_dst, e_c + (16 * i * p.ldc + 32 * jp) * 2, 0, 0);
+            if constexpr (DIAG == 2) asm volatile("" ::"v"(x0), "v"(x1), "v"(y0), "v"(y1));
+            else __builtin_amdgcn_raw_buffer_store_b128((u32x4){x0, x1, y0, y1}, rc_dst, e_c + (16 * i * p.ldc + 32 * jp) * 2, 0, 0);
         }
     };
 
@@ -291,8 +301,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
 }
 
 template <bool B_KMAJOR>
-void launch_pp(int epi, int grid, const GemmParams& p, hipStream_t s) {
+void launch_pp(int epi, int grid, const GemmParams& p, hipStream_t s, int diag = 0) {
     dim3 g(grid), b(NT);
+    if constexpr (!B_KMAJOR) {   // diagnostic builds: NT only, fc1 (GELU) and plain bf16 epilogues
+        if (diag == 1 && epi == EPI_GELU) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_GELU, 1>), g, b, 0, s, p); return; }
+        if (diag == 2 && epi == EPI_GELU) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_GELU, 2>), g, b, 0, s, p); return; }
+        if (diag == 3 && epi == EPI_GELU) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_GELU, 3>), g, b, 0, s, p); return; }
+        if (diag == 1 && epi == EPI_BF16) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_BF16, 1>), g, b, 0, s, p); return; }
+    }
     switch (epi) {
         case EPI_BF16: hipLaunchKernelGGL((gemm_pp_kernel<B_KMAJOR, EPI_BF16>), g, b, 0, s, p); break;
         case EPI_GELU: hipLaunchKernelGGL((gemm_pp_kernel<B_KMAJOR, EPI_GELU>), g, b, 0, s, p); break;
@@ -316,7 +332,7 @@ static int pp_epilogue(int flags) {
 // (layout TN, K % 64 != 0 or K < 512, N % 128 != 0, another epilogue, operands beyond the 2 GiB buffer-descriptor range).
 int gemm_pp_dispatch(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int flags,
                      const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out, int ldaux, float* colsum,
-                     void* stream) {
+                     void* stream, int diag) {
     const int epi = pp_epilogue(flags);
     if (epi < 0 || layout == 2 || K % BK != 0 || K < EPI_STEPS * BK || N % BN != 0) return -2;
     if (epi == EPI_GELU && !aux_out) return -2;
@@ -337,7 +353,7 @@ int gemm_pp_dispatch(int layout, int M, int N, int K, const void* A, int lda, co
     const int tiles = p.tiles_m * p.tiles_n;
     const int grid = tiles >= 512 ? 512 : (tiles + 7) / 8 * 8;   // two workgroups per CU; a multiple of 8 (XCD runs)
     if (b_kmajor) launch_pp<true>(epi, grid, p, (hipStream_t)stream);
-    else launch_pp<false>(epi, grid, p, (hipStream_t)stream);
+    else launch_pp<false>(epi, grid, p, (hipStream_t)stream, diag);
     MH_LAUNCH_CHECK();
     return 0;
 }

@@ -2,6 +2,7 @@
 applied gradient is the mean over ranks."""
 
 import os
+import queue
 
 import pytest
 import torch
@@ -83,3 +84,134 @@ def test_two_ranks_stay_in_sync():
         assert same_grad, f"rank {rank}: all-reduced gradients differ between ranks"
         assert scale == 0.5 and same_params and finite, (rank, scale, same_params, finite)
         assert buckets >= 2, "gradient exchange should be split into several overlapped buckets"
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The FULL launch plan (PretrainLoop.step: backward segments with the gradient hook, buckets overlapped with the backward,
+# GradSync.finish_split + the two-part AdamW under which the head bucket is reduced, hipGraph replay from the second step on)
+# for 5 optimizer steps on two gloo ranks sharing the card, against ONE process that runs the concatenated batch with the
+# concatenated mask draws: what Lightning's DDP gives the reference (maestro/conf/trainer.py:9-14) -- every rank holds the
+# same parameters, and they are the parameters of the large-batch run.
+def _build_single_groups():
+    import maestro_amd.conf as conf
+    from maestro_amd.ssl.mae import mae_tiny
+    # single-modality groups only: then every sample masks the same number of tokens per modality and the mean of the ranks'
+    # losses IS the loss of the concatenated batch (model.py:241-243 averages over the masked pixels of the whole batch)
+    ds = conf.DatasetsConfig(name_dataset="treesatai_ts", treesatai_ts=conf.TreeSatAITSConfig(
+        filter_inputs=["aerial", "s2"], filter_targets=[],
+        aerial=conf.InputRasterConfig(image_size=60, patch_size=conf.PatchSizeConfig(mae=20), bands=4, norm_bands=[1, 3], norm_fac=255.0)))
+    torch.manual_seed(0)
+    model = mae_tiny(datasets=ds, mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=1,
+                     model="mae", num_levels=1, depth=2)
+    return ds, model
+
+
+def _record_draws(eng, log):
+    inner = eng.draw_masks
+
+    def draw():
+        noise, struct = inner()
+        log.append(({g: t.clone() for g, t in noise.items()}, {g: t.clone() for g, t in struct.items()}))
+        return noise, struct
+
+    eng.draw_masks = draw
+
+
+def _plan_worker(rank, world, port, out, bucket_dtype, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from maestro_amd.train.trainer import PretrainLoop, synthetic_batch
+    dev = torch.device("cuda:0")
+    ds, model = _build_single_groups()
+    if rank == 1:      # the ranks start from DIFFERENT weights: PretrainLoop's broadcast must bring rank 0's everywhere
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.01)
+    # (3 MB buckets: the tail of this small model's buffer goes out under the backward, the head stays for finish_split)
+    loop = PretrainLoop(model, 2, dev, base_lr=3e-3, total_steps=20, world_size=world, bucket_mb=3,
+                        bucket_dtype=torch.bfloat16 if bucket_dtype == "bf16" else None)
+    eng, draws, losses, splits = loop.engine, [], [], []
+    _record_draws(eng, draws)
+    inner_split = loop.sync.finish_split
+
+    def finish_split():
+        r = inner_split()
+        splits.append(r[1])
+        return r
+
+    loop.sync.finish_split = finish_split
+    batch = synthetic_batch(ds.dataset, 2, dev, seed=rank)
+    torch.manual_seed(100 + rank)
+    for _ in range(steps):
+        losses.append(float(loop.step(batch).item()))
+    torch.cuda.synchronize()
+    flat = eng.store.flat.cpu()
+    allp = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(allp, flat)
+    # (numpy arrays travel through the queue by value; torch tensors would be passed as shared-memory handles that die with this process)
+    draws_np = [({g: t.numpy() for g, t in n.items()}, {g: t.numpy() for g, t in s.items()}) for n, s in draws]
+    splits = [(s, eng.store.total, sorted(loop.sync.launched)) if s == 0 else s for s in splits]   # (diagnostics when the split is empty)
+    out.put((rank, all(torch.equal(allp[0], p) for p in allp), flat.numpy() if rank == 0 else None, draws_np, losses, splits,
+             len(eng._graphs), {k: v.cpu().numpy() for k, v in batch.items()}))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_dtype", ["f32", "bf16"])
+def test_full_plan_two_ranks_equal_the_concatenated_batch(bucket_dtype):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    steps = 5
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 30900 + os.getpid() % 1000 + (7 if bucket_dtype == "bf16" else 0)
+    procs = [ctx.Process(target=_plan_worker, args=(r, 2, port, out, bucket_dtype, steps)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        for _ in range(120):
+            try:
+                item = out.get(timeout=1)
+                res[item[0]] = item
+                break
+            except queue.Empty:
+                assert all(p.exitcode in (None, 0) for p in procs), "a rank crashed"
+        else:
+            raise AssertionError("ranks did not report within 120 s")
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        _, same_params, _, draws, losses, splits, n_graphs, _ = res[rank]
+        assert same_params, f"rank {rank}: parameters differ between the ranks after {steps} steps of the full plan"
+        assert len(draws) == steps and all(l == l for l in losses)
+        assert all(isinstance(s, int) and s > 0 for s in splits), f"finish_split must leave the head bucket to the two-part AdamW (splits {splits})"
+        assert n_graphs >= 2, "the backward segments should have been captured (hipGraph replay from step 2 on)"
+    if bucket_dtype == "bf16":
+        return          # bf16 buckets round every gradient before the sum: rank consistency is the claim, not large-batch equality
+    # ---- the same 5 steps in ONE process on the concatenated batch with the concatenated draws
+    from maestro_amd.train.trainer import PretrainLoop
+    dev = torch.device("cuda:0")
+    ds, model = _build_single_groups()
+    loop = PretrainLoop(model, 4, dev, base_lr=3e-3, total_steps=20, world_size=1)
+    eng = loop.engine
+    init = eng.store.flat.cpu().clone()                       # = rank 0's seeded initial weights, in the engine's flat order
+    log = iter(zip(res[0][3], res[1][3]))
+
+    def draw():
+        (n0, s0), (n1, s1) = next(log)
+        cat = lambda a, b: torch.cat([torch.from_numpy(a), torch.from_numpy(b)])  # noqa: E731
+        return {g: cat(n0[g], n1[g]) for g in n0}, {g: cat(s0[g], s1[g]) for g in s0}
+
+    eng.draw_masks = draw
+    batch = {k: torch.cat([torch.from_numpy(res[0][7][k]), torch.from_numpy(res[1][7][k])]).to(dev) for k in res[0][7]}
+    single_losses = [float(loop.step(batch).item()) for _ in range(steps)]
+    torch.cuda.synchronize()
+    flat_single, flat_dp = eng.store.flat.cpu(), torch.from_numpy(res[0][2])
+    # the update itself (not the parameters, which are dominated by their initial values) must agree
+    upd_single, upd_dp = flat_single - init, flat_dp - init
+    rel = ((upd_single - upd_dp).double().norm() / upd_single.double().norm()).item()
+    assert upd_single.abs().max().item() > 0 and rel < 2e-2, f"update of the 2-rank run differs from the large-batch run: rel L2 {rel:.3e}"
+    for a, b0, b1 in zip(single_losses, res[0][4], res[1][4]):
+        assert abs(a - 0.5 * (b0 + b1)) < 2e-3 * abs(a), (a, b0, b1)     # mean of the ranks' losses = the large batch's loss
