@@ -75,7 +75,8 @@ enum { MH_TILE_AUTO = -1, MH_TILE_REG_128 = 0, MH_TILE_DMA_256 = 1, MH_TILE_DMA_
        MH_TILE_DMA_128 = 4, MH_TILE_DMA_128x4 = 5, MH_TILE_DMA_256_LOCKSTEP = 6, MH_TILE_PP_128 = 7,
        /* diagnostic builds of MH_TILE_PP_128 (NT only; outputs are NOT the GEMM's): main loop only / epilogue arithmetic without
         * its stores / stores without the GELU arithmetic -- the ablation under profiles/ (scripts/bench_pp_ablate.py) */
-       MH_TILE_PP_128_DIAG1 = 8, MH_TILE_PP_128_DIAG2 = 9, MH_TILE_PP_128_DIAG3 = 10 };
+       MH_TILE_PP_128_DIAG1 = 8, MH_TILE_PP_128_DIAG2 = 9, MH_TILE_PP_128_DIAG3 = 10,
+       MH_TILE_PP_128_DIAG4 = 11, MH_TILE_PP_128_DIAG5 = 12   /* full epilogue, other instruction placements */ };
 int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                       int ldaux, float* colsum, void* stream);

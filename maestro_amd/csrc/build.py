@@ -20,7 +20,7 @@ LIB_DIR = CSRC.parent / "lib"
 LIB = LIB_DIR / "libmaestro_hip.so"
 OBJ_DIR = CSRC / "build"
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"] + os.environ.get("MH_BUILD_FLAGS", "").split()
 # Per-file code-generation flags.  attn.hip: keep the MFMA accumulators in VGPRs -- the softmax reads every score on the
 # VALU, and with AGPR accumulators each tile paid 64-160 v_accvgpr_read/write moves (VALU-bound kernels: -25..-40 % cycles).
 # -fno-slp-vectorize + scalar source (ATTN_SCALAR_VALU, default 1): packed v_pk_fma_f32 / v_pk_add_f32 beside MFMAs are no faster

@@ -80,16 +80,32 @@ __device__ __forceinline__ void gelu_cdf_pdf(float x, float& cdf, float& pdf) {
     pdf = 0.3989422804014327f * e;
 }
 // Four elements at once for the GEMM epilogues, where this arithmetic is NOT hidden: at K = 768 the fc1 GEMM ran 49 us with a plain
-// bias epilogue and 67 us with the GELU (scripts/bench_gelu_cost.py).  Abramowitz-Stegun 7.1.25 (three terms, |error| <= 2.5e-5 on
-// erf: far below what the bf16 activation -- 4e-3 relative -- and the byte-coded derivative -- 2.5e-3 absolute -- resolve) with the
-// constants folded: 15 issue slots per element (rcp and exp2 count two each) instead of 19 for the five-term 7.1.26 above.
-//   z = |x| / sqrt2, t = 1 / (1 + p z), h = 0.5 (a1 t + a2 t^2 + a3 t^3) exp(-z^2) = 1 - Phi(|x|);  Phi(x) = x >= 0 ? 1 - h : h
+// bias epilogue and 67 us with the GELU (scripts/bench_gelu_cost.py); inside the persistent kernel's main loop the arithmetic
+// alone still adds 30 % (profiles/r03_gemm_pp_diag.txt: MFMA and VALU share the SIMD's issue port).
+//   z = |x| / sqrt2, t = 1 / (1 + p z), h = 0.5 poly(t) exp(-z^2) = 1 - Phi(|x|);  Phi(x) = x >= 0 ? 1 - h : h
+// MH_GELU_TERMS = 3 (default): Abramowitz-Stegun 7.1.25, |error| <= 2.5e-5 on erf (far below what the bf16 activation -- 4e-3
+// relative -- and the byte-coded derivative -- 2.5e-3 absolute -- resolve); 5 (-DMH_GELU_TERMS=5 through MH_BUILD_FLAGS): A-S 7.1.26,
+// |error| <= 1.5e-7, two FMAs per element more.  Round 3 measured the five-term form again, now inside the persistent kernel
+// (profiles/r03_gemm_pp_diag.txt): the fc1 GEMMs take 6.6 ... 8.6 % longer (full / main-loop-only 1.44 / 1.40 / 1.62 / 1.83 against
+// 1.34 / 1.31 / 1.50 / 1.69 on the four fc1 shapes), ~0.13 ms = 0.7 % of the C3 step: the epilogue's arithmetic is NOT free even
+// when interleaved with the next tile's MFMAs, so the three-term form stays.
+#ifndef MH_GELU_TERMS
+#define MH_GELU_TERMS 3
+#endif
 __device__ __forceinline__ void gelu_cdf_pdf4(const f32x4 x, f32x4& cdf, f32x4& pdf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(x[i]), 0.47047f * 0.70710678118654752f, 1.f));
         const float e = __builtin_amdgcn_exp2f((x[i] * x[i]) * (-0.5f * 1.4426950408889634f));      // exp(-x^2 / 2)
+#if MH_GELU_TERMS == 3
+        const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(x[i]), 0.47047f * 0.70710678118654752f, 1.f));
         const float poly = __builtin_fmaf(__builtin_fmaf(0.5f * 0.7478556f, t, 0.5f * -0.0958798f), t, 0.5f * 0.3480242f);
+#else
+        const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(x[i]), 0.3275911f * 0.70710678118654752f, 1.f));
+        float poly = __builtin_fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+        poly = __builtin_fmaf(poly, t, 0.5f * 1.421413741f);
+        poly = __builtin_fmaf(poly, t, 0.5f * -0.284496736f);
+        poly = __builtin_fmaf(poly, t, 0.5f * 0.254829592f);
+#endif
         const float h = (poly * t) * e;
         cdf[i] = x[i] >= 0.f ? 1.f - h : h;
         pdf[i] = e * 0.3989422804014327f;

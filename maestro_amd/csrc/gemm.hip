@@ -210,7 +210,7 @@ static bool prefer_dma(int layout, int M, int N, int K, int flags) {
 extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                                  void* C, int ldc, int flags, const float* bias, const float* res, int ldr,
                                  const void* aux_in, void* aux_out, int ldaux, float* colsum, void* stream) {
-    MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_PP_128_DIAG3, "mh_gemm_bf16: tile %d", tile);
+    MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_PP_128_DIAG5, "mh_gemm_bf16: tile %d", tile);
     MH_CHECK_ARG(layout >= 0 && layout <= 2, "mh_gemm_bf16: layout %d", layout);
     MH_CHECK_ARG(M > 0 && N > 0 && K > 0, "mh_gemm_bf16: empty problem %d %d %d", M, N, K);
     MH_CHECK_ARG(A && B && C, "mh_gemm_bf16: null operand");

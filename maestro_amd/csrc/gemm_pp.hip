@@ -235,8 +235,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
         if constexpr (CHUNK >= 0) epi_math(chunk_c, prev);
         // schedule: [first-half fragment reads] [epilogue operand loads] [8 x (2 MFMA, 1 DS write, 1 VMEM read, VALU)]
         //           [second-half reads] [8 x (2 MFMA, VALU)] [epilogue stores]
-        constexpr int NV = CHUNK < 0 ? 0 : EPI == EPI_GELU ? 14 : EPI == EPI_MULAUX ? 6 : EPI == EPI_F32 ? 2 : 2;   // VALU / slot
+        // The epilogue's VALU instructions are NOT pinned: measured on the fc1 shapes (scripts/bench_pp_ablate.py, us):
+        //   no VALU groups (the scheduler's own placement) 54.9 / 78.8 / 68.2 / 184.5   <- this
+        //   NV0 VALU behind every pair of MFMAs (DIAG 4)    57.7 / 80.7 / 70.4 / 184.7
+        //   2 NV0 behind each group of fragment reads + the rest behind the MFMA pairs (DIAG 5)  57.1 / 80.4 / 70.0 / 190.8
+        constexpr int NV0 = CHUNK < 0 ? 0 : EPI == EPI_GELU ? 14 : EPI == EPI_MULAUX ? 6 : EPI == EPI_F32 ? 2 : 2;   // VALU / slot
+        constexpr int NV = DIAG == 4 ? NV0 : DIAG == 5 ? (NV0 * 4 + 6) / 7 : 0;
+        constexpr int NR = DIAG == 5 ? NV0 * 2 : 0;                                   // VALU behind each read group
         __builtin_amdgcn_sched_group_barrier(0x100, B_KMAJOR ? 12 : 8, 0);
+        if constexpr (NR > 0) __builtin_amdgcn_sched_group_barrier(0x402, NR, 0);
         constexpr int NL = CHUNK < 0 ? 0 : (EPI == EPI_F32 || EPI == EPI_MULAUX ? 2 : 0) + ((EPI == EPI_F32 || EPI == EPI_GELU) && (CHUNK & 3) == 0 ? 2 : 0);
         if constexpr (NL > 0) __builtin_amdgcn_sched_group_barrier(0x020, NL, 0);   // the epilogue's operand loads
 #pragma unroll
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
             if constexpr (NV > 0) __builtin_amdgcn_sched_group_barrier(0x402, NV, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x100, B_KMAJOR ? 12 : 8, 0);
+        if constexpr (NR > 0) __builtin_amdgcn_sched_group_barrier(0x402, NR, 0);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -307,6 +315,8 @@ void launch_pp(int epi, int grid, const GemmParams& p, hipStream_t s, int diag =
         if (diag == 1 && epi == EPI_GELU) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_GELU, 1>), g, b, 0, s, p); return; }
         if (diag == 2 && epi == EPI_GELU) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_GELU, 2>), g, b, 0, s, p); return; }
         if (diag == 3 && epi == EPI_GELU) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_GELU, 3>), g, b, 0, s, p); return; }
+        if (diag == 4 && epi == EPI_GELU) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_GELU, 4>), g, b, 0, s, p); return; }
+        if (diag == 5 && epi == EPI_GELU) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_GELU, 5>), g, b, 0, s, p); return; }
         if (diag == 1 && epi == EPI_BF16) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_BF16, 1>), g, b, 0, s, p); return; }
     }
     switch (epi) {

@@ -3,7 +3,9 @@ C3 step's fc1 / qkv shapes, interleaved rounds in one process:
   main    main loop only (no epilogue at all)
   valu    + the epilogue's arithmetic interleaved in the next tile's main loop, results discarded (no global stores)
   stores  + the epilogue's stores (bf16 + byte code), arithmetic replaced by moves
-  full    the kernel
+  full    the kernel (the epilogue's VALU instructions placed by the compiler's scheduler)
+  valu pinned / valu behind reads   the full kernel with the epilogue's VALU instructions pinned behind every MFMA pair / partly
+          behind the fragment reads (sched_group_barrier)
   reg128  the one-tile-per-workgroup kernel (epilogue exposed, LDS-staged) with the same epilogue, and with a plain bf16 one"""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +26,7 @@ for M, N, K in [(8192, 3072, 768), (11392, 3072, 768), (12800, 3072, 512), (3276
     def run(tile, fl):
         kw = dict(bias=bias, aux_out=aux, ldaux=N) if fl else {}
         return lambda: hip.gemm(0, M, N, K, A, K, W, K, C, N, fl, tile=tile, **kw)
-    v = {"main": run(8, FC1), "valu": run(9, FC1), "stores": run(10, FC1), "full": run(hip.TILE_PP_128, FC1),
+    v = {"main": run(8, FC1), "valu": run(9, FC1), "stores": run(10, FC1), "full": run(hip.TILE_PP_128, FC1), "valu pinned": run(11, FC1), "valu behind reads": run(12, FC1),
          "pp plain": run(hip.TILE_PP_128, 0), "pp plain main": run(8, 0), "reg128 gelu": run(hip.TILE_REG_128, FC1), "reg128 plain": run(hip.TILE_REG_128, 0)}
     res = {k: [] for k in v}
     for f in v.values(): f()
