@@ -239,7 +239,7 @@ extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, cons
     MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || !(flags & ~(MH_GEMM_ATOMIC | MH_GEMM_OUT_F32)),
                  "mh_gemm_bf16: atomic accumulate excludes other epilogues");
 
-    if (tile >= MH_TILE_PP_128)
+    if (tile >= MH_TILE_PP_128 && tile <= MH_TILE_PP_128_DIAG5)
         return gemm_pp_dispatch(layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, stream,
                                 tile - MH_TILE_PP_128);
     if (tile > MH_TILE_REG_128)   // explicit DMA tile: -2 when not eligible (the caller picks another tile)
@@ -247,10 +247,10 @@ extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, cons
     // Persistent 128x128 tile with the epilogue inside the next tile's main loop (gemm_pp.hip), scripts/bench_pp.py on the C3
     // step's shapes with their real epilogues: +6...12 % on the plain bf16 NT outputs (qkv), +3...10 % on fp32 + residual
     // (out-proj, fc2) and on the plain NN dgrads, +3 % on fc1; it LOSES 8-20 % on the fc2 dgrad (MULAUX + column sums: 256
-    // VGPRs, spills) -> never picked there.  Against the 256x256 LDS-DMA tile (M = 32768) it wins only the short-K NT problems
-    // without the GELU (qkv 64.6 vs 68.1 us, out-proj 38.9 vs 43.4 us).
+    // VGPRs, spills) -> never picked there.  Against the 256x256 LDS-DMA tile (M = 32768) it wins the short-K NT problems
+    // (qkv 61.0 vs 68.4 us, out-proj 38.8 vs 43.3, fc1 165 vs 173) and loses the long-K ones (fc2 136 vs 125).
     const bool dma = tile == MH_TILE_AUTO && prefer_dma(layout, M, N, K, flags);
-    if (tile == MH_TILE_AUTO && !(flags & MH_GEMM_MULAUX) && (!dma || (layout == 0 && K < 1024 && !(flags & MH_GEMM_GELU)))) {
+    if (tile == MH_TILE_AUTO && !(flags & MH_GEMM_MULAUX) && (!dma || (layout == 0 && K < 1024))) {
         const int rc = gemm_pp_dispatch(layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, stream);
         if (rc != -2) return rc;   // -2: not eligible -> the kernels below
     }

@@ -171,6 +171,9 @@ typedef Tile<2, 2, 3> T256x128;  // 256 x 128
 typedef Tile<1, 4, 3> T128x256;  // 128 x 256
 typedef Tile<1, 2, 4> T128;      // 128 x 128, two 128 x 64 waves
 typedef Tile<2, 2, 4, 4> T128q;  // 128 x 128, four 64 x 64 waves
+// (round 3 also tried Tile<4, 2, 4, 4> / Tile<2, 4, 4, 4>: 256 x 128 / 128 x 256 with EIGHT 64 x 64 waves, staggered, one workgroup
+//  per CU -- 20-45 % slower than the 128^2 kernels on every shape of the step, profiles/r03_gemm_pp_ablation.txt: at 0.5 LDS reads
+//  and 3 DMA pieces per 16 MFMAs a wave's load phase is longer than its partner's math phase)
 
 // Grouped weight-gradient launch: ONE grid over the 256x256 tiles of many independent TN problems
 // (dW_i[M_i, N_i] = dY_i^T X_i, K_i = tokens), no split-K.  Workgroup b (placed on XCD b % 8 by the hardware) runs entry

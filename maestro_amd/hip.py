@@ -145,7 +145,7 @@ def _uses_pp(layout, M, N, K, flags) -> bool:  # noqa: N803
     served = flags in (0, BIAS | GELU | AUX_DGELU | AUX_U8, OUT_F32 | BIAS | RESIDUAL)
     if not served or layout == GEMM_TN or K % 64 or K < 512 or N % 128:
         return False
-    return not _uses_dma(layout, M, N, K, flags) or (layout == GEMM_NT and K < 1024 and not (flags & GELU))
+    return not _uses_dma(layout, M, N, K, flags) or (layout == GEMM_NT and K < 1024)
 
 
 def _auto_tile_name(layout, M, N, K, flags) -> int:  # noqa: N803

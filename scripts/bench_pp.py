@@ -33,7 +33,7 @@ for name, lay, M, N, K, fl in cases:
     cs = torch.empty((M + 63) // 64, N, device=dev) if fl & hip.COLSUM else None
     kw = dict(bias=bias if fl & hip.BIAS else None, res=res, ldr=N if res is not None else 0, ldaux=N if aux is not None else 0,
               aux_out=aux if fl & hip.AUX_DGELU else None, aux_in=aux if fl & hip.MULAUX else None, colsum=cs)
-    variants = {"reg128": hip.TILE_REG_128, "pp128": hip.TILE_PP_128, "auto": hip.TILE_AUTO}
+    variants = {"reg128": hip.TILE_REG_128, "pp128": hip.TILE_PP_128, "auto": hip.TILE_AUTO, "d256": hip.TILE_DMA_256}
     res_t = {k: [] for k in variants}
     ok = {}
     for k, t in variants.items():
@@ -50,7 +50,7 @@ for name, lay, M, N, K, fl in cases:
     for k in variants:
         if ok[k]:
             mn, md = min(res_t[k]), statistics.median(res_t[k])
-            line += f" | {k} {mn:7.1f} us (med {md:7.1f}) {flop / mn / 1e6:6.0f} TF"
+            line += f" | {k} {mn:6.1f} {flop / mn / 1e6:5.0f}TF"
             tot.setdefault(k, 0.0); tot[k] += mn * (9 if M in (8192, 3200) else 3)
         else:
             line += f" | {k}      n/a"
