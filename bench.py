@@ -411,6 +411,10 @@ def main() -> None:
                     out["whole_step"]["hbm_frac"] = round(whole / (elapsed / args.steps) / (HBM_PEAK_TBS * 1e12), 4)
             out["roofline"]["measured_over"] = f"{args.steps} eagerly launched single-stream steps right after the timed region"
             out["kernel_times_ms_per_step"] = timer.summary(args.steps)
+            # the HBM-bound sub-stages separately, as achieved GB/s on their ALGORITHMIC bytes (same eager leg,
+            # HIP events on the launch stream); peak = 8 TB/s (the guide measures 6.3 TB/s for a streaming copy).  Most of these
+            # launches move 30-100 MB in 8-25 us: the launch ramp alone (~2 us) caps them well below a long stream's rate.
+            out["hbm_substages"] = timer.hbm_substages(HBM_PEAK_TBS * 1e3)
         if timer is not None and args.shapes:
             for ms, kind, shape, n, tf in timer.by_shape(args.steps)[:40]:
                 print(f"{ms:8.3f} ms/step {kind:18s} {str(shape):26s} x{n:3d}/step {tf:7.1f} TFLOP/s", file=sys.stderr)

@@ -188,10 +188,25 @@ def call(name: str, *args) -> None:
     _check(getattr(lib(), name)(*conv, stream()), name)
 
 
+def _hbm_call(kind: str, nbytes: float, name: str, *args) -> None:
+    """``call`` bracketed by HIP events when a ``KernelTimer`` is active: the HBM-bound sub-stages report achieved GB/s on
+    their ALGORITHMIC bytes (bench.py's ``hbm_substages``)."""
+    if _timer is None:
+        return call(name, *args)
+    e0, e1 = _timer.record_bytes(kind, nbytes)
+    e0.record()
+    call(name, *args)
+    e1.record()
+
+
+def _esz(t) -> int:
+    return 0 if t is None else t.element_size()
+
+
 # ------------------------------------------------------------------------------------------------ typed wrappers
 def layernorm_fwd(x, x_L, x_off, gamma, beta, y, y_L, y_off, mean, rstd, B, n, dim, eps=1e-5):
-    call("mh_layernorm_fwd", x, _I(x_L), _I(x_off), gamma, beta, y, _I(y_L), _I(y_off),
-         _I(1 if y.dtype == torch.float32 else 0), mean, rstd, _I(B), _I(n), _I(dim), _F(eps))
+    _hbm_call(f"ln_fwd<{dim}>", float(B) * n * dim * (4 + _esz(y)), "mh_layernorm_fwd", x, _I(x_L), _I(x_off), gamma, beta, y, _I(y_L),
+              _I(y_off), _I(1 if y.dtype == torch.float32 else 0), mean, rstd, _I(B), _I(n), _I(dim), _F(eps))
 
 
 def layernorm_fwd_fp8(x, x_L, x_off, gamma, beta, y, y_L, y_off, mean, rstd, B, n, dim, y8, y8_scale, y8_amax, eps=1e-5):
@@ -208,14 +223,16 @@ def layernorm_bwd_workspace(rows, dim) -> int:
 
 def layernorm_bwd(dy, dy_L, dy_off, x, x_L, x_off, gamma, mean, rstd, dres, dx, dx_bf16, dgamma, dbeta, dcol, workspace,
                   B, n, dim):
-    call("mh_layernorm_bwd", dy, _I(dy_L), _I(dy_off), _I(1 if dy.dtype == torch.float32 else 0), x, _I(x_L), _I(x_off),
-         gamma, mean, rstd, dres, dx, dx_bf16, dgamma, dbeta, dcol, workspace, _I(B), _I(n), _I(dim))
+    _hbm_call(f"ln_bwd<{dim}>", float(B) * n * dim * (_esz(dy) + 4 + _esz(dres) + 4 + _esz(dx_bf16)), "mh_layernorm_bwd", dy, _I(dy_L),
+              _I(dy_off), _I(1 if dy.dtype == torch.float32 else 0), x, _I(x_L), _I(x_off), gamma, mean, rstd, dres, dx, dx_bf16,
+              dgamma, dbeta, dcol, workspace, _I(B), _I(n), _I(dim))
 
 
 def layernorm_bwd_partial(dy, dy_L, dy_off, x, x_L, x_off, gamma, mean, rstd, dres, dx, dx_bf16, workspace, B, n, dim):
     """LayerNorm backward that leaves (dgamma | dbeta | colsum(dx)) as per-block partial rows in ``workspace`` (see ColsumBatch)."""
-    call("mh_layernorm_bwd_partial", dy, _I(dy_L), _I(dy_off), _I(1 if dy.dtype == torch.float32 else 0), x, _I(x_L), _I(x_off),
-         gamma, mean, rstd, dres, dx, dx_bf16, workspace, _I(B), _I(n), _I(dim))
+    _hbm_call(f"ln_bwd<{dim}>", float(B) * n * dim * (_esz(dy) + 4 + _esz(dres) + 4 + _esz(dx_bf16)), "mh_layernorm_bwd_partial", dy,
+              _I(dy_L), _I(dy_off), _I(1 if dy.dtype == torch.float32 else 0), x, _I(x_L), _I(x_off), gamma, mean, rstd, dres, dx,
+              dx_bf16, workspace, _I(B), _I(n), _I(dim))
 
 
 COLSUM_ROWS = 16   # MH_COLSUM_ROWS in include/maestro_hip.h
@@ -264,8 +281,10 @@ def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):
 
 
 def patchify(img, cols, target, BD, Ctot, S, P, Kpad, norm_bands, n_groups, normalise, rescale_elev):
-    call("mh_patchify", img, cols, target, _I(BD), _I(Ctot), _I(S), _I(P), _I(Kpad), norm_bands, _I(n_groups),
-         _I(int(normalise)), _I(int(rescale_elev)))
+    # 4 B read per pixel + the bf16 GEMM columns (K padded to Kpad) + the fp32 loss target
+    nb = float(BD) * S * S * Ctot * 4 + float(BD) * (S // P) ** 2 * (Kpad * 2 * (cols is not None) + Ctot * P * P * 4 * (target is not None))
+    _hbm_call("patchify", nb, "mh_patchify", img, cols, target, _I(BD), _I(Ctot), _I(S), _I(P), _I(Kpad), norm_bands, _I(n_groups),
+              _I(int(normalise)), _I(int(rescale_elev)))
 
 
 def patchify_bands(img, cols, target, BD, Csrc, c0, Ctot, S, P, Kpad, norm_bands, n_groups, normalise, rescale_elev):
@@ -348,8 +367,9 @@ def masked_loss_bands(rec, target, mask_group, n_elems, weight, acc, drec, B, Lm
 
 
 def masked_loss(rec, target, mask_group, n_masked, weight, acc, drec, B, Lm, Lgroup, tok_off, PPC, p):
-    call("mh_masked_loss", rec, target, mask_group, n_masked, _F(weight), acc, drec, _I(B), _I(Lm), _I(Lgroup),
-         _I(tok_off), _I(PPC), _I(p))
+    # per element: reconstruction (bf16) + target (f32) read, d loss / d rec (bf16) written; + one mask byte per token
+    _hbm_call("masked_loss", float(B) * Lm * (PPC * (_esz(rec) + 4 + _esz(drec)) + 1), "mh_masked_loss", rec, target, mask_group,
+              n_masked, _F(weight), acc, drec, _I(B), _I(Lm), _I(Lgroup), _I(tok_off), _I(PPC), _I(p))
 
 
 def dihedral(x, out, flags):
@@ -439,7 +459,8 @@ def unpack_rows_add(src, dst, E, K, Kpad):
 
 
 def adamw(p, g, m, v, p_bf16, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
-    call("mh_adamw", p, g, m, v, p_bf16, _L(n), _F(lr), _F(b1), _F(b2), _F(eps), _F(wd), _I(step), _F(grad_scale))
+    _hbm_call("adamw", float(n) * (16 + 12 + _esz(p_bf16)), "mh_adamw", p, g, m, v, p_bf16, _L(n), _F(lr), _F(b1), _F(b2), _F(eps), _F(wd),
+              _I(step), _F(grad_scale))
 
 
 def adamw_fp8(p, g, m, v, p_bf16, p_fp8, slot_map, scale, amax, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
@@ -469,7 +490,7 @@ def adamw_bias_corrections(b1: float, b2: float, step: int) -> tuple[float, floa
 
 def adamw_dev(p, g, m, v, p_bf16, n, b1, b2, eps, wd, hyper):
     """AdamW with {lr, 1 - b1^t, sqrt(1 - b2^t), grad_scale, active} read from the device tensor ``hyper`` (graph-capturable)."""
-    call("mh_adamw_dev", p, g, m, v, p_bf16, _L(n), _F(b1), _F(b2), _F(eps), _F(wd), hyper)
+    _hbm_call("adamw", float(n) * (16 + 12 + _esz(p_bf16)), "mh_adamw_dev", p, g, m, v, p_bf16, _L(n), _F(b1), _F(b2), _F(eps), _F(wd), hyper)
 
 
 # ------------------------------------------------------------------------------------------------ kernel timing
@@ -481,6 +502,7 @@ class KernelTimer:
         self.flops: dict[str, float] = {}
         self.count: dict[str, int] = {}
         self.shapes: dict = {}
+        self.hbm: dict[str, list] = {}      # HBM-bound sub-stages: kind -> [(e0, e1, algorithmic bytes)]
 
     def record(self, kind: str, flops: float, shape=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -490,6 +512,23 @@ class KernelTimer:
         self.flops[kind] = self.flops.get(kind, 0.0) + flops
         self.count[kind] = self.count.get(kind, 0) + 1
         return e0, e1
+
+    def record_bytes(self, kind: str, nbytes: float):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.hbm.setdefault(kind, []).append((e0, e1, nbytes))
+        return e0, e1
+
+    def hbm_substages(self, peak_gbs: float) -> dict:
+        """Per HBM-bound kernel: achieved GB/s = algorithmic bytes / HIP-event duration, summed over its launches."""
+        torch.cuda.synchronize()
+        out = {}
+        for kind, evs in sorted(self.hbm.items()):
+            ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+            nb = sum(n for _, _, n in evs)
+            if ms > 0:
+                out[kind] = {"gb_s": round(nb / ms / 1e6, 1), "frac": round(nb / ms / 1e6 / peak_gbs, 3), "launches": len(evs),
+                             "avg_us": round(1e3 * ms / len(evs), 2), "mb_per_launch": round(nb / len(evs) / 1e6, 2)}
+        return out
 
     def totals(self) -> dict[str, float]:
         torch.cuda.synchronize()

@@ -30,6 +30,9 @@ def short(name):
     m = re.match(r"gemm_dma_kernel<Tile<([\d, ]+)>, (\w+), (\w+)(?:, \w+)?>", name)   # (+ the STAGGER flag since round 2)
     if m:
         return f"gemm_dma_kernel<{_TILE[m.group(1)]},{_LAYOUT[(m.group(2), m.group(3))]}>"
+    m = re.match(r"gemm_pp_kernel<(\w+), \d+(?:, \d+)?>", name)      # (B_KMAJOR, epilogue form[, diagnostic build])
+    if m:
+        return f"gemm_pp_kernel<{'NN' if m.group(1) == 'true' else 'NT'}>"
     if name.startswith("gemm_dma_grouped_tn_kernel"):
         return "gemm_dma_grouped_tn_kernel"
     return name.split("(")[0]
