@@ -76,7 +76,10 @@ enum { MH_TILE_AUTO = -1, MH_TILE_REG_128 = 0, MH_TILE_DMA_256 = 1, MH_TILE_DMA_
        /* diagnostic builds of MH_TILE_PP_128 (NT only; outputs are NOT the GEMM's): main loop only / epilogue arithmetic without
         * its stores / stores without the GELU arithmetic -- the ablation under profiles/ (scripts/bench_pp_ablate.py) */
        MH_TILE_PP_128_DIAG1 = 8, MH_TILE_PP_128_DIAG2 = 9, MH_TILE_PP_128_DIAG3 = 10,
-       MH_TILE_PP_128_DIAG4 = 11, MH_TILE_PP_128_DIAG5 = 12   /* full epilogue, other instruction placements */ };
+       MH_TILE_PP_128_DIAG4 = 11, MH_TILE_PP_128_DIAG5 = 12,  /* full epilogue, other instruction placements */
+       /* MH_TILE_REG_128's kernel with 64 x 128 tiles (three workgroups per CU) / 192 x 128 tiles: for outputs whose 128 x 128
+        * tiling fills the chip's workgroup slots badly (N = 512 / 768).  NT / NN without MH_GEMM_COLSUM; otherwise = REG_128. */
+       MH_TILE_REG_64 = 13, MH_TILE_REG_192 = 14 };
 int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                       int ldaux, float* colsum, void* stream);
@@ -293,6 +296,16 @@ int mh_unmask_assemble(const float* y, const int* inv, const float* mask_token, 
  * [t_lo, t_hi) whose tok_slot == slot (atomic). */
 int mh_unmask_token_grad(const float* dxdec, const uint8_t* mask, const int* tok_slot, float* dmask_token, int B, int L,
                          int Dd, int slot, int t_lo, int t_hi, void* stream);
+/* The same two with a PER-SAMPLE slot map tok_slot_bl int32 [B, L]: masked position t of sample b receives mask token
+ * tok_slot_bl[b, t].  Serves the reference's implementation-defined tie order (maestro/ssl/mae.py:274-286:
+ * mask_rec.float().argsort(descending=True) orders the masked positions of a sample arbitrarily, so in a group of several
+ * modalities a position can receive ANOTHER modality's token); the host builds the map from the same torch call
+ * (MAEEngine.tie_order = "torch").  The gradient sums over all masked positions of the group whose map entry == slot. */
+int mh_unmask_assemble_per_sample(const float* y, const int* inv, const float* mask_token, const int* tok_slot_bl,
+                                  const float* pos, const float* date, const int* date_row, int n_date_rows, float* xdec,
+                                  int B, int L, int n_vis, int Dd, void* stream);
+int mh_unmask_token_grad_per_sample(const float* dxdec, const uint8_t* mask, const int* tok_slot_bl, float* dmask_token, int B,
+                                    int L, int Dd, int slot, void* stream);
 /* out[0] = number of masked tokens of all samples in group positions [t_lo, t_hi) (one modality). */
 int mh_count_masked(const uint8_t* mask, int B, int L, int t_lo, int t_hi, int* out, void* stream);
 /* out[0] = (accumulate ? out[0] : 0) + mult * that count: the masked ELEMENTS of a modality whose band-groups have different

@@ -17,15 +17,17 @@ typedef __attribute__((address_space(3))) unsigned char lds_u8;
 __device__ __forceinline__ int kmajor_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
 // ---- global -> registers (4 x 16 B per thread per operand tile)
-template <bool KMAJOR>
+// NI = 16-byte pieces per thread = (tile rows) / 32 for a K-minor operand (4: 128 rows; 2: 64; 6: 192); K-major tiles are 128 wide
+template <bool KMAJOR, int NI = 4>
 __device__ __forceinline__ void load_tile(const bf16_t* __restrict__ P, int ld, int row0, int nrows, int k0, int kend,
-                                          u32x4 (&v)[4]) {
+                                          u32x4 (&v)[NI]) {
+    static_assert(!KMAJOR || NI == 4, "K-major operand tiles are 128 columns wide");
     const int t = threadIdx.x;
     if constexpr (!KMAJOR) {  // memory: P[row * ld + k]
         const int c = t & 7, r = t >> 3;
         const int gk = k0 + c * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int grow = row0 + r + 32 * i;
             u32x4 z = {0, 0, 0, 0};
             if (grow < nrows && gk < kend) z = *reinterpret_cast<const u32x4*>(P + (size_t)grow * ld + gk);
@@ -47,32 +49,35 @@ __device__ __forceinline__ void load_tile(const bf16_t* __restrict__ P, int ld, 
 // ---- fast path: buffer loads.  The 128-bit resource descriptor carries the exact byte extent of the operand, so rows
 // beyond M / N (K-minor) or beyond K (K-major) read as zero in hardware; per-thread byte offsets are loop-invariant
 // 32-bit VGPRs and the K advance is ONE scalar offset -> no per-step predication, no 64-bit vector address math.
-template <bool KMAJOR>
-__device__ __forceinline__ void tile_offsets(int ld, int row0, int (&voff)[4]) {
+template <bool KMAJOR, int NI = 4>
+__device__ __forceinline__ void tile_offsets(int ld, int row0, int (&voff)[NI]) {
+    static_assert(!KMAJOR || NI == 4, "K-major operand tiles are 128 columns wide");
     const int t = threadIdx.x;
     if constexpr (!KMAJOR) {
         const int c = t & 7, r = t >> 3;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) voff[i] = ((row0 + r + 32 * i) * ld + c * 8) * 2;
+        for (int i = 0; i < NI; ++i) voff[i] = ((row0 + r + 32 * i) * ld + c * 8) * 2;
     } else {
         const int c = t & 15, kk = t >> 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) voff[i] = ((kk + 16 * i) * ld + row0 + c * 8) * 2;
     }
 }
-__device__ __forceinline__ void load_tile_fast(__amdgpu_buffer_rsrc_t rsrc, const int (&voff)[4], int soff, u32x4 (&v)[4]) {
+template <int NI>
+__device__ __forceinline__ void load_tile_fast(__amdgpu_buffer_rsrc_t rsrc, const int (&voff)[NI], int soff, u32x4 (&v)[NI]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], soff, 0);
+    for (int i = 0; i < NI; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], soff, 0);
 }
 
 // ---- registers -> swizzled LDS tile
-template <bool KMAJOR>
-__device__ __forceinline__ void store_tile(unsigned char* tile, const u32x4 (&v)[4]) {
+template <bool KMAJOR, int NI = 4>
+__device__ __forceinline__ void store_tile(unsigned char* tile, const u32x4 (&v)[NI]) {
+    static_assert(!KMAJOR || NI == 4, "K-major operand tiles are 128 columns wide");
     const int t = threadIdx.x;
     if constexpr (!KMAJOR) {
         const int c = t & 7, r = t >> 3;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int row = r + 32 * i;
             *reinterpret_cast<u32x4*>(tile + row * 128 + ((c ^ (row & 7)) << 4)) = v[i];
         }

@@ -89,12 +89,14 @@ __global__ __launch_bounds__(256) void unmask_kernel(const float* __restrict__ y
                                                      const float* __restrict__ mask_token, const int* __restrict__ tok_slot,
                                                      const float* __restrict__ pos, const float* __restrict__ date,
                                                      const int* __restrict__ date_row, int n_date_rows,
-                                                     float* __restrict__ xdec, int B, int L, int n_vis, int Dd) {
+                                                     float* __restrict__ xdec, int B, int L, int n_vis, int Dd, int slot_stride) {
+    // slot_stride: 0 = tok_slot [L] (a position's own mask token: the stable tie order); L = tok_slot [B, L] (per-sample map:
+    // the reference's implementation-defined placement, mh_unmask_assemble_per_sample)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= B * L) return;
     const int b = row / L, t = row - b * L;
     const int iv = inv[row];
-    const float* s = iv < 0 ? mask_token + (size_t)tok_slot[t] * Dd : y + ((size_t)b * n_vis + iv) * Dd;
+    const float* s = iv < 0 ? mask_token + (size_t)tok_slot[(size_t)b * slot_stride + t] * Dd : y + ((size_t)b * n_vis + iv) * Dd;
     const float* pr = pos + (size_t)t * Dd;
     const float* dr = date ? date + ((size_t)b * n_date_rows + date_row[t]) * 8 : nullptr;
     float* o = xdec + (size_t)row * Dd;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void unmask_kernel(const float* __restrict__ y
 constexpr int UM_ROWS = 128;  // rows per block: keeps the same-address atomics per column at B*L/128 instead of B*L/16
 __global__ __launch_bounds__(256) void unmask_bwd_token_kernel(const float* __restrict__ dxdec, const uint8_t* __restrict__ mask,
                                                                const int* __restrict__ tok_slot, float* __restrict__ dmask_token,
-                                                               int B, int L, int Dd, int slot, int t_lo, int t_hi) {
+                                                               int B, int L, int Dd, int slot, int t_lo, int t_hi, int slot_stride) {
     // grid: ceil(B*(t_hi-t_lo) / UM_ROWS); the 256 threads are (row lane, float4 column): Dd/4 <= 256 columns, 256/(Dd/4)
     // rows side by side; four independent row loads in flight per thread (the row predicate is applied to the loaded value's
     // use, not to a branch around a dependent chain: 70 -> ~20 us at 32768 x 512)
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void unmask_bwd_token_kernel(const float* __re
                 v[u] = (f32x4){0, 0, 0, 0};
                 if (rr + u * lanes < UM_ROWS && r < total) {
                     const int b = r / span, t = t_lo + (r - b * span);
-                    if (mask[(size_t)b * L + t] && tok_slot[t] == slot)
+                    if (mask[(size_t)b * L + t] && tok_slot[(size_t)b * slot_stride + t] == slot)
                         v[u] = *reinterpret_cast<const f32x4*>(dxdec + ((size_t)b * L + t) * Dd + 4 * col);
                 }
             }
@@ -203,7 +205,18 @@ extern "C" int mh_unmask_assemble(const float* y, const int* inv, const float* m
     MH_CHECK_ARG(y && inv && mask_token && tok_slot && pos && xdec && Dd % 4 == 0 && Dd >= 8, "mh_unmask_assemble: bad arguments");
     MH_CHECK_ARG(!date || date_row, "mh_unmask_assemble: date without date_row");
     hipLaunchKernelGGL(unmask_kernel, dim3(ceil_div((long)B * L, 4)), dim3(256), 0, (hipStream_t)stream, y, inv, mask_token,
-                       tok_slot, pos, date, date_row, n_date_rows, xdec, B, L, n_vis, Dd);
+                       tok_slot, pos, date, date_row, n_date_rows, xdec, B, L, n_vis, Dd, 0);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_unmask_assemble_per_sample(const float* y, const int* inv, const float* mask_token, const int* tok_slot_bl,
+                                             const float* pos, const float* date, const int* date_row, int n_date_rows,
+                                             float* xdec, int B, int L, int n_vis, int Dd, void* stream) {
+    MH_CHECK_ARG(y && inv && mask_token && tok_slot_bl && pos && xdec && Dd % 4 == 0 && Dd >= 8, "mh_unmask_assemble_per_sample: bad arguments");
+    MH_CHECK_ARG(!date || date_row, "mh_unmask_assemble_per_sample: date without date_row");
+    hipLaunchKernelGGL(unmask_kernel, dim3(ceil_div((long)B * L, 4)), dim3(256), 0, (hipStream_t)stream, y, inv, mask_token,
+                       tok_slot_bl, pos, date, date_row, n_date_rows, xdec, B, L, n_vis, Dd, L);
     MH_LAUNCH_CHECK();
     return 0;
 }
@@ -213,7 +226,17 @@ extern "C" int mh_unmask_token_grad(const float* dxdec, const uint8_t* mask, con
     MH_CHECK_ARG(dxdec && mask && tok_slot && dmask_token && Dd % 4 == 0 && Dd <= 1024, "mh_unmask_token_grad: bad arguments");
     MH_CHECK_ARG(0 <= t_lo && t_lo < t_hi && t_hi <= L, "mh_unmask_token_grad: bad token range");
     hipLaunchKernelGGL(unmask_bwd_token_kernel, dim3(ceil_div((long)B * (t_hi - t_lo), UM_ROWS)), dim3(256), 0,
-                       (hipStream_t)stream, dxdec, mask, tok_slot, dmask_token, B, L, Dd, slot, t_lo, t_hi);
+                       (hipStream_t)stream, dxdec, mask, tok_slot, dmask_token, B, L, Dd, slot, t_lo, t_hi, 0);
+    MH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mh_unmask_token_grad_per_sample(const float* dxdec, const uint8_t* mask, const int* tok_slot_bl, float* dmask_token,
+                                               int B, int L, int Dd, int slot, void* stream) {
+    MH_CHECK_ARG(dxdec && mask && tok_slot_bl && dmask_token && Dd % 4 == 0 && Dd <= 1024 && B > 0 && L > 0,
+                 "mh_unmask_token_grad_per_sample: bad arguments");
+    hipLaunchKernelGGL(unmask_bwd_token_kernel, dim3(ceil_div((long)B * L, UM_ROWS)), dim3(256), 0, (hipStream_t)stream, dxdec, mask,
+                       tok_slot_bl, dmask_token, B, L, Dd, slot, 0, L, L);
     MH_LAUNCH_CHECK();
     return 0;
 }

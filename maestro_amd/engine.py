@@ -513,6 +513,10 @@ class EngineBase:
         self.device = device
         self.grad_hook = None       # callable(lo, hi) invoked when grad[lo:hi] is final (DDP bucket launch)
         self.use_graphs = True      # capture launch segments into hipGraphs once input addresses repeat
+        # "stable" (the build's defined semantics: ties -> ascending index, every masked position gets its own modality's token) or
+        # "torch" (the reference's implementation-defined order, reproduced by issuing its two argsort calls on the host; set it
+        # before the first forward: captured graphs hold the kernels of one mode).  MAESTRO_TIE_ORDER sets the default.
+        self.tie_order = os.environ.get("MAESTRO_TIE_ORDER", "stable")
         self.multi_stream = True    # independent groups on parallel HIP streams
         self.group_streams = os.environ.get("MAESTRO_GROUP_STREAMS") != "0"   # (only with multi_stream)
         # MAESTRO_TUNE=1: the first forward / backward run eagerly on one stream with GEMM tile tuning on: every distinct GEMM
@@ -816,6 +820,34 @@ class MAEEngine(EngineBase):
         D = g.mods[0].Dates  # noqa: N806   sequence (b, band-group, date) of the folded modality -> row (b, date) of this group
         return t.reshape(g.Beff // D, g.draw_G, D, -1)[:, g.draw_g].reshape(g.Beff, -1)
 
+    def _reference_tie_order(self, g, gbuf, noise: torch.Tensor, struct: torch.Tensor, slot: int):
+        """``tie_order = "torch"``: the reference's two unstable sorts, issued on the host exactly as it issues them.
+
+        (a) ``maestro/ssl/mae.py:240-242``: ``argsort(noise * (1 - struct))`` -- structurally masked tokens tie at 0, and when more
+        than k of them tie, WHICH become masked is torch's sort order.  The masked set chosen by that call is handed to
+        ``mh_mask_select`` as a tie-free draw (0 on the chosen tokens, 1 elsewhere): same kernel, the reference's set.
+        (b) ``mae.py:274-286``: ``mask_rec.float().argsort(descending=True)`` orders a sample's masked positions arbitrarily, and the
+        mask tokens (gathered in ascending position order, ``mae.py:259-262``) are scattered in THAT order: in a group of several
+        modalities a position can receive another modality's token.  Returned as a per-sample slot map for
+        ``mh_unmask_assemble_per_sample``.  The default ("stable") keeps ascending ties and every position's own token."""
+        B, L, k = g.Beff, g.L, g.k  # noqa: N806
+        nz = noise * (1 - struct.float())
+        order = torch.argsort(nz, dim=-1)
+        masked = torch.zeros((B, L), dtype=torch.bool)
+        masked.scatter_(1, order[:, :k], True)
+        place = masked.float().argsort(dim=1, descending=True)[:, :k]
+        ascending = order[:, :k].sort(dim=1).values
+        if "tok_slot_host" not in gbuf:
+            gbuf["tok_slot_host"] = gbuf["tok_slot"].cpu()
+            gbuf["tok_slot_ps"] = torch.zeros((B, L), dtype=torch.int32, device=self.device)
+            gbuf["tok_slot_ps_h"] = [torch.zeros((B, L), dtype=torch.int32).pin_memory() for _ in range(RING)]
+        base = gbuf["tok_slot_host"]
+        ps = base[None, :].expand(B, L).clone()
+        ps.scatter_(1, place, base[ascending])
+        gbuf["tok_slot_ps_h"][slot].copy_(ps)
+        gbuf["tok_slot_ps"].copy_(gbuf["tok_slot_ps_h"][slot], non_blocking=True)
+        return (~masked).float(), torch.zeros_like(struct)
+
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, batch: dict, noise: dict | None = None, struct: dict | None = None) -> torch.Tensor:
         """Runs the forward pass + loss; returns the loss as a 1-element device tensor (no host sync)."""
@@ -839,8 +871,11 @@ class MAEEngine(EngineBase):
         for g in self.groups:
             gbuf = self.gb[g.name]
             nh, sh = gbuf["noise_h"][slot], gbuf["struct_h"][slot]
-            nh.copy_(self._rows_of(noise, g))
-            sh.copy_(self._rows_of(struct, g).reshape(g.Beff, g.L))
+            n_g, s_g = self._rows_of(noise, g), self._rows_of(struct, g).reshape(g.Beff, g.L)
+            if self.tie_order == "torch":
+                n_g, s_g = self._reference_tie_order(g, gbuf, n_g, s_g, slot)
+            nh.copy_(n_g)
+            sh.copy_(s_g)
             gbuf["noise"].copy_(nh, non_blocking=True)
             gbuf["struct"].copy_(sh, non_blocking=True)
         if self._opt is not None:      # overlapped optimizer: this step's scalars (or "nothing pending") ride the same ring
@@ -1056,8 +1091,12 @@ class MAEEngine(EngineBase):
                              hip.OUT_F32 | hip.BIAS, bias=lin.bias)
                 for s in g.mods:
                     gbuf["tok_table"][s.slot].copy_(m.mask_token[s.src].view(s.G, Dd)[s.gi])
-                hip.unmask_assemble(gbuf["y_e2d"], gbuf["inv"], gbuf["tok_table"], gbuf["tok_slot"], gbuf["pos_dec"],
-                                    gbuf["dates"], gbuf["date_row"], gbuf["n_dates"], st.x0, g.Beff, g.L, g.N, Dd)
+                if self.tie_order == "torch":   # the reference's placement of mask tokens (per-sample map built on the host)
+                    hip.unmask_assemble_per_sample(gbuf["y_e2d"], gbuf["inv"], gbuf["tok_table"], gbuf["tok_slot_ps"], gbuf["pos_dec"],
+                                                   gbuf["dates"], gbuf["date_row"], gbuf["n_dates"], st.x0, g.Beff, g.L, g.N, Dd)
+                else:
+                    hip.unmask_assemble(gbuf["y_e2d"], gbuf["inv"], gbuf["tok_table"], gbuf["tok_slot"], gbuf["pos_dec"],
+                                        gbuf["dates"], gbuf["date_row"], gbuf["n_dates"], st.x0, g.Beff, g.L, g.N, Dd)
                 if part == "pre":
                     return
                 st.forward(lambda l: self._opt_wait("dec", l))
@@ -1298,8 +1337,12 @@ class MAEEngine(EngineBase):
             # unmask backward: visible rows -> enc_to_dec output grad; masked rows -> mask-token grads
             hip.gather_rows(dx0, gbuf["vis"], gbuf["dy_e2d"], g.Beff, g.L, g.N, Dd, g.N, 0)
             for s in g.mods:
-                hip.unmask_token_grad(dx0, gbuf["mask"], gbuf["tok_slot"], ps.g(m.mask_token[s.src]).view(s.G, Dd)[s.gi], g.Beff,
-                                      g.L, Dd, s.slot, s.tok_off, s.tok_off + s.n_tok)
+                if self.tie_order == "torch":
+                    hip.unmask_token_grad_per_sample(dx0, gbuf["mask"], gbuf["tok_slot_ps"],
+                                                     ps.g(m.mask_token[s.src]).view(s.G, Dd)[s.gi], g.Beff, g.L, Dd, s.slot)
+                else:
+                    hip.unmask_token_grad(dx0, gbuf["mask"], gbuf["tok_slot"], ps.g(m.mask_token[s.src]).view(s.G, Dd)[s.gi], g.Beff,
+                                          g.L, Dd, s.slot, s.tok_off, s.tok_off + s.n_tok)
                 self._ready_spans.append(ps.span([m.mask_token[s.src]]))
             M = g.Beff * g.N  # noqa: N806
             lin = m.enc_to_dec[g.model]

@@ -61,13 +61,15 @@ _I, _F, _L = ctypes.c_int, ctypes.c_float, ctypes.c_long
 # ---- GEMM: kernel / tile choice (include/maestro_hip.h MH_TILE_*)
 TILE_AUTO, TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128, TILE_DMA_128x4 = -1, 0, 1, 2, 3, 4, 5
 TILE_DMA_256_LOCKSTEP = 6   # MH_TILE_DMA_256 without the wave-group stagger (A/B experiments)
+TILE_REG_64, TILE_REG_192 = 13, 14   # the register-staged kernel with 64 x 128 / 192 x 128 tiles
 TILE_PP_128 = 7             # persistent 128x128 tile, epilogue of tile t inside the main loop of tile t + 1 (gemm_pp.hip)
 TILES = (TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128, TILE_DMA_128x4)
 _LAYOUT_NAME = {0: "NT", 1: "NN", 2: "TN"}
 _TILE_NAME = {TILE_REG_128: "gemm_kernel<{}>", TILE_DMA_256: "gemm_dma_kernel<256x256,{}>",
               TILE_DMA_256x128: "gemm_dma_kernel<256x128,{}>", TILE_DMA_128x256: "gemm_dma_kernel<128x256,{}>",
               TILE_DMA_128: "gemm_dma_kernel<128x128,{}>", TILE_DMA_128x4: "gemm_dma_kernel<128x128q,{}>",
-              TILE_DMA_256_LOCKSTEP: "gemm_dma_kernel<256x256,{}>", TILE_PP_128: "gemm_pp_kernel<{}>"}
+              TILE_DMA_256_LOCKSTEP: "gemm_dma_kernel<256x256,{}>", TILE_PP_128: "gemm_pp_kernel<{}>",
+              TILE_REG_64: "gemm_kernel<{},64x128>", TILE_REG_192: "gemm_kernel<{},192x128>"}
 _tile_choice: dict = {}     # (layout, M, N, K, flags) -> fastest tile, filled while tuning is on
 _tuning = False
 
@@ -138,17 +140,27 @@ def _pick_tile(layout, M, N, K, flags, args) -> int:  # noqa: N803
     return tile
 
 
+def _uses_192(layout, M, N, K, flags) -> bool:  # noqa: N803
+    """Mirror of the 192 x 128 rule in csrc/gemm.hip (labels kernel timings only)."""
+    if layout == GEMM_TN or (flags & (COLSUM | ATOMIC)) or K < 1536 or K % 64 or _uses_dma(layout, M, N, K, flags):
+        return False
+    t128 = -(-M // 128) * -(-N // 128)
+    return 512 < t128 <= 576 and -(-M // 192) * -(-N // 128) <= 512
+
+
 def _uses_pp(layout, M, N, K, flags) -> bool:  # noqa: N803
     """Mirror of the MH_TILE_AUTO rule in csrc/gemm.hip + gemm_pp_dispatch's eligibility (labels kernel timings only)."""
     if os.environ.get("MH_GEMM_PP", "")[:1] == "0":
         return False
     served = flags in (0, BIAS | GELU | AUX_DGELU | AUX_U8, OUT_F32 | BIAS | RESIDUAL)
-    if not served or layout == GEMM_TN or K % 64 or K < 512 or N % 128:
+    if not served or layout == GEMM_TN or K % 64 or K < 512 or N % 128 or _uses_192(layout, M, N, K, flags):
         return False
     return not _uses_dma(layout, M, N, K, flags) or (layout == GEMM_NT and K < 1024)
 
 
 def _auto_tile_name(layout, M, N, K, flags) -> int:  # noqa: N803
+    if _uses_192(layout, M, N, K, flags):
+        return TILE_REG_192
     if _uses_pp(layout, M, N, K, flags):
         return TILE_PP_128
     return TILE_DMA_256 if _uses_dma(layout, M, N, K, flags) else TILE_REG_128
@@ -351,6 +363,15 @@ def unmask_assemble(y, inv, mask_token, tok_slot, pos, date, date_row, n_date_ro
 
 def unmask_token_grad(dxdec, mask, tok_slot, dmask_token, B, L, Dd, slot, t_lo, t_hi):
     call("mh_unmask_token_grad", dxdec, mask, tok_slot, dmask_token, _I(B), _I(L), _I(Dd), _I(slot), _I(t_lo), _I(t_hi))
+
+
+def unmask_assemble_per_sample(y, inv, mask_token, tok_slot_bl, pos, date, date_row, n_date_rows, xdec, B, L, n_vis, Dd):
+    call("mh_unmask_assemble_per_sample", y, inv, mask_token, tok_slot_bl, pos, date, date_row, _I(n_date_rows), xdec, _I(B), _I(L),
+         _I(n_vis), _I(Dd))
+
+
+def unmask_token_grad_per_sample(dxdec, mask, tok_slot_bl, dmask_token, B, L, Dd, slot):
+    call("mh_unmask_token_grad_per_sample", dxdec, mask, tok_slot_bl, dmask_token, _I(B), _I(L), _I(Dd), _I(slot))
 
 
 def count_masked(mask, B, L, t_lo, t_hi, out):

@@ -357,6 +357,20 @@ class _RandRecorder:
         torch.rand = self._orig
 
 
+def tie_case_table():
+    """Tie-DEPENDENT cases, kept apart from ``case_table``: in at least one (sample, group) more than k tokens are
+    structurally masked, so WHICH of them the reference masks -- and, in the two-modality s1 group, which mask token lands
+    where -- is decided by the tie order of torch's unstable CPU sorts.  They pin ``MAEEngine.tie_order = "torch"`` and the
+    oracle's ``reference_tie_order`` (which reissue the reference's own calls) against the reference itself."""
+    base = case_table()
+    return {
+        # the seed that case_table avoids for c5 (one sample with #struct-masked > k), plain inputs
+        "ties_c5_s2naip": dict(base["c5_s2naip_stress"], seed=41, stress=False),
+        # heavy structural masking on the C3'-shaped case: ties in the masked set AND the two-modality s1 group
+        "ties_c3p_dem_s1": dict(base["c3p_dem_s1"], seed=6, mask_kw=dict(mask_mod=0.5, mask_dates=0.5, mask_loc=0.5)),
+    }
+
+
 def _tie_free(noise: torch.Tensor, struct: torch.Tensor, k: int) -> bool:
     return bool((struct.reshape(noise.shape).sum(dim=1) <= k).all())
 
@@ -672,7 +686,7 @@ def main() -> None:
     only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None   # optional: comma-separated case names
     if which in ("all", "pretrain"):
         np.savez_compressed(GOLDEN / "layers.npz", **layer_vectors(ref))
-        for name, case in case_table().items():
+        for name, case in {**case_table(), **tie_case_table()}.items():
             if only is not None and name not in only:
                 continue
             out = run_case(name, case, ref, ours)

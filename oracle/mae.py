@@ -82,8 +82,8 @@ class OracleMAE(nn.Module):
                  type_head="attentive", fac_abs_enc=1.0, fac_date_enc=1.0, date_dim=8, **_kw) -> None:
         super().__init__()
         # False (default): stable tie order = the build's defined semantics.  True: reproduce the reference's
-        # implementation-defined placement of mask tokens in ``unmask_seq`` (mae.py:274) by issuing the same
-        # unstable torch.argsort call -- used only to show that the tie order is the SOLE source of divergence.
+        # implementation-defined choices -- the masked set when more than k tokens tie (mae.py:241) and the placement of
+        # mask tokens in ``unmask_seq`` (mae.py:274) -- by issuing the same unstable torch.argsort calls.
         self.reference_tie_order = False
         ds = self.dataset = datasets.dataset
         self.fusion_mode, self.interpolate = fusion_mode, interpolate
@@ -212,7 +212,9 @@ class OracleMAE(nn.Module):
         """
         B, L = noise.shape  # noqa: N806
         noise = noise * (1 - struct.reshape(B, L).float())
-        order = torch.argsort(noise, dim=-1, stable=True)
+        # (reference_tie_order: the reference's own call, ``torch.argsort(noise, dim=-1)`` at mae.py:241 -- unstable, so which of
+        #  more than k structurally masked tokens (all 0) become masked is torch's implementation-defined order)
+        order = torch.argsort(noise, dim=-1) if self.reference_tie_order else torch.argsort(noise, dim=-1, stable=True)
         k = self.num_masked(self.mask_ratio[name_group], L)
         masked = order[:, :k].sort(dim=1).values
         visible = order[:, k:].sort(dim=1).values

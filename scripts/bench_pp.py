@@ -33,7 +33,7 @@ for name, lay, M, N, K, fl in cases:
     cs = torch.empty((M + 63) // 64, N, device=dev) if fl & hip.COLSUM else None
     kw = dict(bias=bias if fl & hip.BIAS else None, res=res, ldr=N if res is not None else 0, ldaux=N if aux is not None else 0,
               aux_out=aux if fl & hip.AUX_DGELU else None, aux_in=aux if fl & hip.MULAUX else None, colsum=cs)
-    variants = {"reg128": hip.TILE_REG_128, "pp128": hip.TILE_PP_128, "auto": hip.TILE_AUTO, "d256": hip.TILE_DMA_256}
+    variants = {"reg128": hip.TILE_REG_128, "pp128": hip.TILE_PP_128, "auto": hip.TILE_AUTO, "reg64": hip.TILE_REG_64, "reg192": hip.TILE_REG_192}
     res_t = {k: [] for k in variants}
     ok = {}
     for k, t in variants.items():

@@ -231,3 +231,32 @@ def test_gemm_pp_declines_what_it_does_not_serve():
         K, N, flags = args.get("K", 512), args.get("N", 256), args.get("flags", 0)
         with pytest.raises(hip.HipExtensionError):
             hip.gemm(0, 256, N, K, A, 512, A, 512, C, 256, flags, bias=torch.zeros(256, device=dev), tile=hip.TILE_PP_128)
+
+
+# ---- MH_TILE_REG_64 / MH_TILE_REG_192: the register-staged kernel with 64 x 128 / 192 x 128 tiles
+@pytest.mark.parametrize("tile_name", ["TILE_REG_64", "TILE_REG_192"])
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("shape", [(200, 136, 192), (1000, 768, 512), (8192, 768, 768), (330, 72, 104)])
+def test_gemm_other_tile_heights(tile_name, layout, shape):
+    from maestro_amd import hip
+    dev = _dev()
+    tile = getattr(hip, tile_name)
+    M, N, K = shape
+    A, B, want = _operands(layout, M, N, K, dev, integer=True)
+    C = torch.full((M + 2, N), 7.0, device=dev)
+    hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], C, N, hip.OUT_F32, tile=tile)
+    torch.cuda.synchronize()
+    assert torch.equal(C[:M], want) and bool((C[M:] == 7.0).all()), f"max diff {(C[:M] - want).abs().max().item()}"
+    # the fused epilogues: bit for bit the 128 x 128 kernel's (same K order per output element, same epilogue code)
+    A, B, _ = _operands(layout, M, N, K, dev, integer=False)
+    g = torch.Generator().manual_seed(2)
+    bias, res = torch.randn(N, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+    for flags, dt, kw in [(0, torch.bfloat16, {}), (hip.BIAS | hip.GELU, torch.bfloat16, dict(bias=bias)),
+                          (hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, torch.float32, dict(bias=bias, res=res, ldr=N))]:
+        outs = []
+        for t in (tile, hip.TILE_REG_128):
+            C = torch.zeros((M, N), device=dev, dtype=dt)
+            hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], C, N, flags, tile=t, **kw)
+            outs.append(C)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]), (flags, (outs[0].float() - outs[1].float()).abs().max().item())
