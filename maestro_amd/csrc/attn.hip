@@ -22,6 +22,11 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef ATTN_SCALAR_VALU
 #define ATTN_SCALAR_VALU 1
 #endif
+// ATTN_DIAG (diagnostic builds only, WRONG results; MH_ATTN_FLAGS="-DATTN_DIAG=n"): what is one VALU issue slot per score worth?
+//   bit 0: forward without the row-sum adds;  bit 1: backward without the scale / lse FMA and without the "- delta" add
+#ifndef ATTN_DIAG
+#define ATTN_DIAG 0
+#endif
 __device__ __forceinline__ f32x4 fms4(f32x4 a, float c, f32x4 b) {   // a * c - b
 #if ATTN_SCALAR_VALU
     return (f32x4){__builtin_fmaf(a[0], c, -b[0]), __builtin_fmaf(a[1], c, -b[1]), __builtin_fmaf(a[2], c, -b[2]),
@@ -226,7 +231,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                 const f32x4 t = fms4(s[qt][kt], c, mc4);
                 const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
                 s[qt][kt] = pv;
-#if ATTN_SCALAR_VALU
+#if ATTN_DIAG & 1
+                p0 = pv[0];
+#elif ATTN_SCALAR_VALU
                 p0 += pv[0]; p1 += pv[1]; p2 += pv[2]; p3 += pv[3];
 #else
                 ps4 += pv;
@@ -382,9 +389,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             const f32x4 nd4 = {-dlt[qt], -dlt[qt], -dlt[qt], -dlt[qt]};
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
+#if ATTN_DIAG & 2
+                const f32x4 t = s[qt][kt];
+                const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
+                s[qt][kt] = pv * dp[qt][kt];
+#else
                 const f32x4 t = fms4(s[qt][kt], c, l4);
                 const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
                 s[qt][kt] = mul_add4(pv, dp[qt][kt], nd4);  // dS / scale; the factor is applied to dQ once at the end
+#endif
             }
             dsf[qt][0] = pack_acc(s[qt][0], s[qt][1]);
             dsf[qt][1] = pack_acc(s[qt][2], s[qt][3]);
@@ -506,10 +519,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
             const f32x4 nd4 = *reinterpret_cast<const f32x4*>(s_dlt + 16 * qt + 4 * g);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
+#if ATTN_DIAG & 2
+                const f32x4 t = s[qt][kt];
+                const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
+                s[qt][kt] = pv;
+                dp[qt][kt] = pv * dp[qt][kt];
+#else
                 const f32x4 t = fms4(s[qt][kt], c, l4);                // query >= N: lse2 = +inf -> probability 0
                 const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
                 s[qt][kt] = pv;
                 dp[qt][kt] = mul_add4(pv, dp[qt][kt], nd4);            // dS / scale (applied to dK at the end)
+#endif
             }
         }
 #pragma unroll
