@@ -9,7 +9,7 @@ A = torch.randn((M, K) if layout < 2 else (K, M), device=dev).bfloat16()
 B = torch.randn((N, K) if layout == 0 else (K, N), device=dev).bfloat16()
 C = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
 os.environ["MH_GEMM_DMA"] = "0"
-kw = {"impl": "dma"} if impl == "dma" else {}
+kw = {"tile": int(impl[4:])} if impl.startswith("tile") else {}      # "tile<k>": an explicit MH_TILE_* id (7 = the ping-pong tile, 8.. its diagnostic builds)
 bias, aux = torch.randn(N, device=dev), torch.empty(M, N, device=dev, dtype=torch.uint8)
 for _ in range(20):
     if epi == "gelu":
