@@ -39,38 +39,18 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {   // ONE v_cv
 }
 
 // ----------------------------------------------------------------------------- wave / block reductions
-// Whole-wave reductions by DPP (data-parallel primitives of the VALU: one v_add_f32_dpp per step) instead of six dependent
-// ds_bpermute round trips through the LDS crossbar (what __shfl_xor compiles to on gfx950).  row_shr:1,2,4,8 leave every 16-lane
-// row's sum in its lane 15; row_bcast:15 / :31 carry it into the next row(s); lane 63 holds the total, read back as a scalar.
-// (Round 3, scripts/bench_ln.py with 50 launches per hipGraph: the LayerNorm kernels take the same time with either form --
-// forward 7.5 us = 5.0 TB/s, backward 19.5 us = 5.2 TB/s at 8192 x 768 against 5.3 / 13.0 us for plain copies of the same bytes --
-// they are bound by their loads, not by the reductions; kept because it frees the LDS pipe and six waits per reduction.)
-// All 64 lanes must be active (callers reduce under wave-uniform control flow only).
-template <int CTRL, int ROW_MASK, bool BOUND_CTRL>
-__device__ __forceinline__ float dpp_mov0(float v) {   // lanes without a source (or masked rows) read 0
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND_CTRL));
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_mov_self(float v) {   // lanes without a source (or masked rows) keep their own value
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-}
+// (Round 3 tried DPP reductions here -- row_shr:1,2,4,8 + row_bcast:15 / :31, one v_add_f32_dpp per step instead of six
+//  ds_bpermute round trips: the LayerNorm / loss kernels take the same time with either form (scripts/bench_ln.py: they are bound
+//  by their loads, not by the reductions), so the shuffle form stays.)
 __device__ __forceinline__ float wave_sum(float v) {
-    v += dpp_mov0<0x111, 0xf, true>(v);    // row_shr:1
-    v += dpp_mov0<0x112, 0xf, true>(v);    // row_shr:2
-    v += dpp_mov0<0x114, 0xf, true>(v);    // row_shr:4
-    v += dpp_mov0<0x118, 0xf, true>(v);    // row_shr:8
-    v += dpp_mov0<0x142, 0xa, false>(v);   // row_bcast:15 -> rows 1, 3
-    v += dpp_mov0<0x143, 0xc, false>(v);   // row_bcast:31 -> rows 2, 3
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, dpp_mov_self<0x111, 0xf>(v));
-    v = fmaxf(v, dpp_mov_self<0x112, 0xf>(v));
-    v = fmaxf(v, dpp_mov_self<0x114, 0xf>(v));
-    v = fmaxf(v, dpp_mov_self<0x118, 0xf>(v));
-    v = fmaxf(v, dpp_mov_self<0x142, 0xa>(v));
-    v = fmaxf(v, dpp_mov_self<0x143, 0xc>(v));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
 }
 // Block-wide sum for blockDim.x = 64*NW threads; `red` is NW floats of LDS. Result broadcast to all threads.
 template <int NW>

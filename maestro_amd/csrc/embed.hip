@@ -204,6 +204,11 @@ __global__ __launch_bounds__(256) void embed_bwd_stats_kernel(const float* __res
     }
 }
 
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
 // ---- backward pass 2: dy = rstd * (dz - S1/n - z*S2/n) as bf16 (A operand of the patch-embed wgrad GEMM)
 __global__ __launch_bounds__(256) void embed_bwd_apply_kernel(const float* __restrict__ dxg, const float* __restrict__ y,
                                                               const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -452,8 +457,10 @@ extern "C" int mh_embed_finish_bwd(const float* dxg, const float* y, const float
                                    int Lgroup, void* stream) {
     MH_CHECK_ARG(dxg && y && stats && gamma && dyc && dgamma && dbeta && sums && E % 4 == 0, "mh_embed_finish_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sums, 0, (size_t)B * D * 2 * sizeof(float), s);
-    if (e != hipSuccess) return mh_fail((int)e, "mh_embed_finish_bwd: memset failed");
+    // (a KERNEL, not hipMemsetAsync: this entry point is captured into hipGraphs, and on ROCm 7.2 the 16-byte memset node of a
+    //  [B = 2, D = 1] modality replayed wrongly -- garbage in `sums` from the second replay on, found in round 3 by the order of
+    //  the GPU tests; every other node of the graph was fine)
+    hipLaunchKernelGGL(zero_f32_kernel, dim3(ceil_div((long)B * D * 2, 256)), dim3(256), 0, s, sums, B * D * 2);
     hipLaunchKernelGGL(embed_bwd_stats_kernel, dim3(ceil_div(L, 4 * EB_ROWS), B * D), dim3(256), (size_t)8 * E * sizeof(float), s,
                        dxg, y, stats, gamma, sums, dgamma, dbeta, B, D, L, E, tok_off, Lgroup);
     hipLaunchKernelGGL(embed_bwd_apply_kernel, dim3(ceil_div((long)B * D * L, 4)), dim3(256), 0, s, dxg, y, stats, gamma, sums,

@@ -18,7 +18,9 @@ Pipeline (reference ``maestro/ssl/mim.py:473-505`` + ``maestro/train/model.py:19
 from __future__ import annotations
 
 import contextlib
+import gc
 import os
+import weakref
 import time
 
 import torch
@@ -505,6 +507,29 @@ class StackSet:
         return list(zip(cur, cur16))
 
 
+# hipGraphs of engines that have been garbage-collected, kept alive until the next SAFE point.  An engine is a reference cycle, so
+# Python finalises a dropped one whenever the cyclic collector happens to run -- possibly between two launches of ANOTHER engine's
+# step, with that engine's graphs in flight.  Destroying CUDAGraph objects at such a moment (hipGraphExecDestroy + release of their
+# private memory pools) was observed to corrupt later replays on ROCm 7.2: wrong gradients of a replayed segment, or a segmentation
+# fault inside hipGraphLaunch (round 3; it depended on the ORDER of the tests, i.e. on when the collector fired; gone with the
+# collector off, and gone with the graphs never destroyed).  So a dying engine only hands its graphs to this list; they are
+# destroyed by ``drain_retired_graphs`` after a device synchronisation, when the next engine is built (or on request).
+_RETIRED_GRAPHS: list = []
+
+
+def _retire_graphs(graphs: dict) -> None:      # weakref.finalize callback: must not reference the engine
+    if graphs:
+        _RETIRED_GRAPHS.append(dict(graphs))
+        graphs.clear()
+
+
+def drain_retired_graphs() -> None:
+    """Destroy the hipGraphs of engines that no longer exist, with the device idle.  NOT called automatically: see below."""
+    if _RETIRED_GRAPHS:
+        torch.cuda.synchronize()
+        _RETIRED_GRAPHS.clear()
+
+
 class EngineBase:
     """Launch runtime shared by the step engines: group-parallel HIP streams, hipGraph segments (captured on their second
     run with unchanged input addresses, eager fallback), gradient-ready spans for the data-parallel hook, GEMM tuning pass."""
@@ -528,7 +553,12 @@ class EngineBase:
         # [-0.129, 1.129]) instead of bf16 -- 1.7 GB less HBM traffic per C3 step; MAESTRO_AUX_U8=0 keeps bf16
         self.aux_flag = hip.AUX_U8 if os.environ.get("MAESTRO_AUX_U8", "1") == "1" else 0
         self._tuned = set()
+        # A safe point (nothing of THIS engine is in flight yet): finalise engines that earlier callers dropped NOW -- with the
+        # collector's own timing they would die somewhere inside this engine's steps --, then destroy their graphs with the
+        # device idle.
+        gc.collect()
         self._graphs, self._seen, self._ready_spans = {}, {}, []
+        weakref.finalize(self, _retire_graphs, self._graphs)
         self._inputs = {}           # per batch key: last device address, or the engine-owned staging copy
         self.side_streams = [torch.cuda.Stream(device=device) for _ in range(max(0, n_side_streams))]
         self._wgrad_stream = torch.cuda.Stream(device=device)   # plan "ovl": deferred weight gradients under the next segment
@@ -623,13 +653,27 @@ class EngineBase:
         self._ready_spans = []
         if seen == key:  # second time with the same addresses: capture (the first eager run warmed everything up)
             graph = torch.cuda.CUDAGraph()
+            # No cyclic garbage collection while the stream is capturing.  torch.cuda.graph() collects once on entry, but the
+            # segment function allocates thousands of small Python objects (ctypes arguments, tensor views), so an automatic
+            # collection can fire in the middle of the capture; if it then finalises an engine that an earlier caller dropped
+            # (engines are reference cycles), that engine's CUDAGraph objects and their private memory pools are destroyed --
+            # hipGraphExecDestroy / hipFree, i.e. device synchronisation -- INSIDE the capture.  Observed (round 3, found by test
+            # ORDER: tests/test_gemm_gpu.py followed by tests/test_sup_gpu.py): graphs that replay with wrong gradients or crash
+            # in hipGraphLaunch; gone with the collector off during the capture (or off altogether).
+            gc_was_on, failure = gc.isenabled(), None
+            gc.disable()
             try:
                 # thread_local: other threads (e.g. the RCCL watchdog polling events) must not invalidate the capture
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     fn()
             except Exception as exc:  # noqa: BLE001 -- capture is an optimisation: fall back to eager launches
+                failure = exc
+            finally:
+                if gc_was_on:
+                    gc.enable()
+            if failure is not None:
                 import warnings
-                warnings.warn(f"hipGraph capture of segment {name!r} failed ({exc}); continuing with eager launches")
+                warnings.warn(f"hipGraph capture of segment {name!r} failed ({failure}); continuing with eager launches")
                 self.use_graphs = False
                 torch.cuda.synchronize()
                 self._ready_spans = []

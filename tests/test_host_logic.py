@@ -376,3 +376,40 @@ def test_module_log_helpers_and_state_dict_surface():
                          sync_dist=True)]
     assert "_anchor" not in mod.state_dict() and all(n != "_anchor" for n, _ in mod.named_parameters())
     assert mod._anchor.requires_grad and mod._anchor.is_leaf
+
+
+def test_dropped_engines_retire_their_graphs(monkeypatch):
+    """An engine that gets garbage-collected must NOT destroy its hipGraphs on the spot (the cyclic collector can run between two
+    launches of another engine's step; destroying graphs then corrupted later replays on ROCm 7.2): they are handed to a module
+    list and destroyed at the next safe point, after a device synchronisation (``drain_retired_graphs``)."""
+    import gc
+    import weakref
+
+    import torch
+
+    from maestro_amd import engine
+
+    class FakeEngine:
+        def __init__(self):
+            self._graphs = {}
+            self.me = self                                   # a reference cycle, like the real engines
+            weakref.finalize(self, engine._retire_graphs, self._graphs)
+
+    destroyed = []
+
+    class FakeGraph:
+        def __del__(self):
+            destroyed.append(1)
+
+    monkeypatch.setattr(engine, "_RETIRED_GRAPHS", [])
+    synced = []
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: synced.append(1))
+    e = FakeEngine()
+    e._graphs["forward"] = {"key": 1, "graph": FakeGraph(), "spans": []}
+    del e
+    gc.collect()
+    assert not destroyed and len(engine._RETIRED_GRAPHS) == 1, "the graph must outlive its engine until the next safe point"
+    engine.drain_retired_graphs()
+    assert destroyed == [1] and synced == [1] and not engine._RETIRED_GRAPHS
+    engine.drain_retired_graphs()                            # nothing retired: no synchronisation
+    assert synced == [1]

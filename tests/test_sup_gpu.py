@@ -54,7 +54,21 @@ def test_supervised_engine_matches_oracle_and_reference(golden_dir, name, phase,
             first, grad0 = loss.item(), eng.store.grad.clone()
         else:
             assert abs(loss.item() - first) <= 1e-5 * abs(first)
-            assert ((eng.store.grad - grad0).norm() / grad0.norm()).item() < 1e-4
+            rel = ((eng.store.grad - grad0).norm() / grad0.norm()).item()
+            if not rel < 1e-4:      # which parameters differ between the eager and the replayed backward?
+                bad = []
+                for k, p in model.named_parameters():
+                    if id(p) not in eng.store.offset:
+                        continue
+                    o = eng.store.offset[id(p)]
+                    a, b0 = eng.store.grad[o: o + p.numel()], grad0[o: o + p.numel()]
+                    d = ((a - b0).norm() / b0.norm().clamp(min=1e-20)).item()
+                    if not d < 1e-4:
+                        bad.append((k, d, a.flatten()[:3].tolist(), b0.flatten()[:3].tolist()))
+                info = {n: (float(b["dw_conv"].abs().max()), float(b["dyc"].float().abs().max()), float(b["cols"].float().abs().max()))
+                        for n, b in eng.mb.items()}
+                raise AssertionError(f"iteration {it}: replayed gradients differ from the eager ones (rel {rel:.3e}); graphs "
+                                     f"{list(eng._graphs)}; parameters: {bad[:8]}; |dw_conv|, |dyc|, |cols| max per modality: {info}")
     logits = eng.logits()
 
     ob, _, _, ologits = oracle({k: v.clone() for k, v in batch.items()}, phase)
