@@ -22,7 +22,7 @@ from oracle import mae as om
 from oracle.gen_golden import init_weights
 
 pytestmark = pytest.mark.gpu
-LOSS_TOL, PIX_TOL, GRAD_TOL = 1e-3, 2e-2, 4.5e-2
+LOSS_TOL, PIX_TOL, GRAD_TOL = 7e-4, 1.4e-2, 3.1e-2     # the full-width tolerances (<= 2x observed there); here: 1.7e-4, -, 1.1e-2
 COMMON = dict(interpolate="nearest", fusion_mode="group", inter_depth=3, model="mae", num_levels=1)
 
 

@@ -106,9 +106,9 @@ def test_gemm_fp8_epilogues_match_bf16_kernel(dev):
 
 COMMON = dict(interpolate="nearest", model="mae", num_levels=1, type_head="attentive", fac_abs_enc=1.0, fac_date_enc=1.0)
 # fp8 forward (e4m3, 3 mantissa bits) against the fp32 oracle: observed on MI355X (round 2) loss 4.2e-4, pixels_rec 5.6e-2,
-# worst parameter gradient 8.6e-2 (relative L2) -- tolerances <= 3x; the bf16 engine sits at 3.5e-4 / 7e-3 / 1.5e-2
-FP8_LOSS_TOL, FP8_PIX_TOL, FP8_GRAD_TOL = 1.2e-3, 1.5e-1, 2.5e-1
-FP8_DGRAD_TOL = 0.3    # opt-in e5m2 data-gradient GEMMs (2 mantissa bits): observed worst 0.104
+# worst parameter gradient 8.6e-2 (relative L2) -- tolerances <= 2x; the bf16 engine sits at 3.5e-4 / 7e-3 / 1.5e-2
+FP8_LOSS_TOL, FP8_PIX_TOL, FP8_GRAD_TOL = 8.4e-4, 1.12e-1, 1.72e-1
+FP8_DGRAD_TOL = 0.208    # opt-in e5m2 data-gradient GEMMs (2 mantissa bits): observed worst 0.104
 
 
 @pytest.mark.parametrize("dgrad", ["0", "1"])

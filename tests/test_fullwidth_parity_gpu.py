@@ -26,7 +26,7 @@ from oracle.gen_golden import init_weights
 
 pytestmark = pytest.mark.gpu
 
-LOSS_TOL, PIX_TOL, GRAD_TOL = 1e-3, 2e-2, 4.5e-2   # observed worst: 3.5e-4 (C4), 6.9e-3 (C3' s1_asc), 1.53e-2 (C5)
+LOSS_TOL, PIX_TOL, GRAD_TOL = 7e-4, 1.4e-2, 3.1e-2   # <= 2x the observed worst: 3.5e-4 (C4), 6.9e-3 (C3' s1_asc), 1.53e-2 (C5)
 COMMON = dict(interpolate="nearest", fusion_mode="group", inter_depth=3, model="mae", num_levels=1)
 
 

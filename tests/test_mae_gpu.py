@@ -1,13 +1,13 @@
 """End-to-end GPU parity of the HIP engine: forward, masks, loss and every parameter gradient vs the oracle and vs
 the REFERENCE's golden vectors (tests/golden/*.npz), same weights, same inputs, same injected RNG draws.
 
-Tolerances (bf16 MFMA GEMMs/attention with fp32 accumulation and fp32 residual stream vs an fp32 CPU oracle), set to <= 3x
-the worst error observed over all golden cases on MI355X (round 2, final code with the byte-coded GELU derivative,
-gpurun_out/observed_full.jsonl: loss 9.9e-4, pixels_rec 4.9e-3, worst parameter gradient 1.45e-2; l1 losses 1.1e-2):
+Tolerances (bf16 MFMA GEMMs/attention with fp32 accumulation and fp32 residual stream vs an fp32 CPU oracle), set to <= 2x
+the worst error observed over all golden cases on MI355X (round 3, profiles/r03_observed_errors.jsonl: loss 1.04e-3,
+pixels_rec 4.9e-3, worst parameter gradient 1.51e-2):
   mask indices ............ bit-exact
-  loss .................... |d| <= 3e-3 * |loss|
-  pixels_rec .............. relative L2 error <= 1.3e-2 per modality
-  parameter gradients ..... relative L2 error <= 3.5e-2 per parameter (plus an absolute floor for ~zero grads)
+  loss .................... |d| <= 2.1e-3 * |loss|
+  pixels_rec .............. relative L2 error <= 1e-2 per modality
+  parameter gradients ..... relative L2 error <= 3e-2 per parameter (plus an absolute floor for ~zero grads)
 """
 
 import numpy as np
@@ -22,7 +22,7 @@ from oracle.gen_golden import build_datasets, case_table, init_weights, make_bat
 pytestmark = pytest.mark.gpu
 CASES = case_table()
 TIE_CASES = tie_case_table()
-LOSS_TOL, PIX_TOL, GRAD_TOL = 3e-3, 1.3e-2, 3.5e-2
+LOSS_TOL, PIX_TOL, GRAD_TOL = 2.1e-3, 1e-2, 3e-2
 COMMON = dict(interpolate="nearest", model="mae", num_levels=1, type_head="attentive", fac_abs_enc=1.0, fac_date_enc=1.0)
 
 

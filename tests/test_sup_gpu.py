@@ -18,7 +18,7 @@ from oracle import heads as oh
 from tests.test_oracle_sup import CASES, build_sup_case
 
 pytestmark = pytest.mark.gpu
-LOSS_TOL, LOGIT_TOL, GRAD_TOL = 1.2e-3, 1.6e-2, 4.2e-2    # <= 3x observed on MI355X (round 2): 4.1e-4, 5.3e-3, 1.4e-2
+LOSS_TOL, LOGIT_TOL, GRAD_TOL = 8e-4, 1.1e-2, 2.9e-2    # <= 2x observed on MI355X (round 3): 3.8e-4, 5.3e-3, 1.42e-2
 
 
 def _rel(a, b):
