@@ -170,13 +170,24 @@ class EngineDDPCallback:
     """Lightning recipe for several GPUs (duck-typed ``pytorch_lightning.Callback``: only the hooks below are used).
 
     Run the ``Trainer`` with ONE device per process (``strategy="auto", devices=1`` under ``torchrun``, process group
-    initialised by the launcher) and add this callback: it broadcasts rank 0's weights once the engine exists and sums the
-    engine's flat gradient buffer after every backward, before the optimizer step reads ``p.grad``.  ``DistributedDataParallel``
-    itself cannot be used: the engine's gradients do not come from autograd hooks."""
+    initialised by the launcher) and add this callback: it broadcasts rank 0's weights before the first forward and averages
+    the engine's flat gradient buffer over the ranks in every backward, before the optimizer step reads ``p.grad``.
+    ``DistributedDataParallel`` itself cannot be used: the engine's gradients do not come from autograd hooks.
 
-    def __init__(self, bucket_mb: int = 64, group=None) -> None:
+    ``overlap=True`` (default): as with Lightning's DDP reducer, the buckets go out WHILE the backward runs.  The callback
+    becomes the engine's ``grad_exchange``: the autograd bridge (``train/model.py:_EngineLoss.backward``) brackets
+    ``engine.backward()`` with ``begin_exchange`` / ``finish_exchange``; the engine cuts its backward into segments and hands
+    every finished gradient slice to ``GradSync.ready`` (the launch plan of ``PretrainLoop`` under data parallelism), and what
+    the bridge still owes the buffer -- d loss scaling, the 1 / world_size of the mean, the accumulated gradients of earlier
+    micro-batches -- is applied AFTER the sum (all linear; done earlier it would race the in-flight all-reduces, which work
+    in place).  ``overlap=False``: one exchange in ``on_after_backward``, after the whole backward."""
+
+    def __init__(self, bucket_mb: int = 64, group=None, overlap: bool = True) -> None:
         self.bucket_bytes, self.group, self._sync, self._engine = bucket_mb << 20, group, None, None
         self._module_synced = False
+        self.overlap = overlap
+        self._exchanged_in_backward = False
+        self._lo = 0
 
     def _sync_module(self, pl_module) -> None:
         """Rank 0's weights BEFORE the first forward, as Lightning's DDP wrap gives them (``maestro/conf/trainer.py:9-14``):
@@ -193,11 +204,36 @@ class EngineDDPCallback:
     def _attach(self, engine) -> None:
         if engine is self._engine:
             return
+        if self._engine is not None and getattr(self._engine, "grad_exchange", None) is self:
+            self._engine.grad_exchange, self._engine.grad_hook = None, None      # a phase change built another engine
         self._engine = engine
         if not self._module_synced:     # direct use without the fit hooks: fall back to the flat-buffer broadcast
             broadcast_parameters(engine, self.group)
             self._module_synced = True
-        self._sync = GradSync(engine.store.grad_all, self.bucket_bytes, self.group, always_ready_from=engine.store.total)
+        st = engine.store
+        # probe: only the heads have gradients -- the buckets cover [lo, total + slot) (as SupervisedLoop's do)
+        lo = self._lo = getattr(engine, "trainable_span", (0, st.total))[0]
+        self._sync = GradSync(st.grad_all[lo:] if lo else st.grad_all, self.bucket_bytes, self.group, always_ready_from=st.total - lo)
+        if self.overlap:
+            engine.grad_hook = (lambda a, b: self._sync.ready(max(a, lo) - lo, b - lo) if b > lo else None) if lo else self._sync.ready
+            engine.grad_exchange = self
+
+    # ---- called by the autograd bridge around engine.backward() (overlap mode)
+    def begin_exchange(self, engine) -> None:
+        loss = getattr(engine, "loss_acc", None)
+        if loss is not None:            # the trailing slot rides in the first bucket: this step's loss (see ``loss_mean``)
+            engine.store.extra[:1].copy_(loss.reshape(-1)[:1])
+        self._sync.begin()
+
+    def finish_exchange(self, engine) -> float:  # noqa: ARG002
+        """Waits for the buckets; returns the factor the bridge folds into its scaling pass (sum -> mean)."""
+        self._exchanged_in_backward = True
+        return self._sync.finish()
+
+    @property
+    def loss_mean(self):
+        """Cross-rank mean of the last exchanged step's loss (device tensor, no collective of its own)."""
+        return self._engine.store.extra[:1] / self._sync.world
 
     def _engine_of(self, pl_module):
         return getattr(pl_module.model, "_engine", None) or getattr(pl_module.model, "_sup_engine", None)
@@ -214,13 +250,22 @@ class EngineDDPCallback:
         if engine is not None and _active(self.group):
             self._attach(engine)
 
+    def on_before_backward(self, trainer, pl_module, loss) -> None:  # noqa: ARG002
+        """The engine of the FIRST step is built inside ``training_step``, after ``on_train_batch_start``: attach it here so
+        that already its backward goes through the overlapped exchange."""
+        engine = self._engine_of(pl_module)
+        if engine is not None and _active(self.group):
+            self._attach(engine)
+
     def on_after_backward(self, trainer, pl_module) -> None:  # noqa: ARG002
-        """The exchange is NOT overlapped with the backward here: the autograd bridge may still rescale / accumulate the
-        buffer after the engine's backward (``_EngineLoss.backward``), so the buckets go out once it has returned."""
+        """Exchange after the whole backward: ``overlap=False``, or a backward that did not go through the bridge."""
         engine = self._engine_of(pl_module)
         if engine is None or not _active(self.group):
             return
         self._attach(engine)
+        if self._exchanged_in_backward:
+            self._exchanged_in_backward = False
+            return
         self._sync.begin()
         scale = self._sync.finish()
         if scale != 1.0:

@@ -162,14 +162,21 @@ class _EngineLoss(torch.autograd.Function):
                 st.grad_acc = torch.empty_like(st.grad)
             st.grad_acc.copy_(st.grad)
         eng.zero_grad()
+        # data parallelism on the Lightning surface (``EngineDDPCallback(overlap=True)``): the buckets of the flat buffer are
+        # all-reduced while the engine's backward runs; everything below is linear and is applied to the SUM
+        exchange = getattr(eng, "grad_exchange", None)
+        if exchange is not None:
+            exchange.begin_exchange(eng)
         eng.backward()
+        mean = exchange.finish_exchange(eng) if exchange is not None else 1.0
         st.fresh = False
         if isinstance(grad_out, torch.Tensor) and grad_out.is_cuda:
             # d loss as a device scalar (autograd's ones, loss / accumulate_grad_batches, a trainer's loss scaling): applied on
             # the device, skipped there when it is 1 -- no host read of the value
-            hip.scale_dev(st.grad, st.total, grad_out.detach().reshape(1).to(torch.float32))
-        elif float(grad_out) != 1.0:
-            st.grad.mul_(float(grad_out))
+            factor = grad_out.detach().reshape(1).to(torch.float32)
+            hip.scale_dev(st.grad, st.total, factor * mean if mean != 1.0 else factor)
+        elif float(grad_out) * mean != 1.0:
+            st.grad.mul_(float(grad_out) * mean)
         if live:
             st.grad.add_(st.grad_acc)
         for p in st.params:  # re-attach views if the trainer cleared them (zero_grad(set_to_none=True))

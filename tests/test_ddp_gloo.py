@@ -109,9 +109,23 @@ class _FakeStore:
 class _FakeEngine:
     def __init__(self, n, rank):
         self.store, self.packed, self.grad_hook = _FakeStore(n, rank), 0, None
+        self.rank, self.loss_acc, self.in_flight = rank, torch.tensor([10.0 * (rank + 1)]), []
 
     def _pack_conv_weights(self):
         self.packed += 1
+
+    def zero_grad(self):
+        pass
+
+    def backward(self):
+        """Tail first, as the real engine: every finished slice is handed to ``grad_hook`` (when one is set)."""
+        st, n = self.store, self.store.total
+        for lo, hi in ((600, n), (250, 600), (0, 250)):
+            st.grad[lo:hi] = torch.arange(lo, hi, dtype=torch.float32) * (self.rank + 1)
+            if self.grad_hook is not None:
+                self.grad_hook(lo, hi)
+                sync = self.grad_exchange._sync
+                self.in_flight.append(list(sync.launched))
 
 
 class _FakeFp8:
@@ -148,7 +162,7 @@ def _slot_worker(rank, world, port, out):
         res[tag] = (first, float((st.grad - want).abs().max()) <= tol * float(want.abs().max()) + 1e-6,
                     float(st.extra[0] * scale))
     # Lightning recipe: one all-reduce + mean after the backward, through the callback's hooks
-    cb = EngineDDPCallback(bucket_mb=1)
+    cb = EngineDDPCallback(bucket_mb=1, overlap=False)
     mod = SimpleNamespace(model=SimpleNamespace(_engine=eng, _sup_engine=None))
     st.flat.fill_(float(rank + 5))
     st.grad.fill_(float(rank + 1))
@@ -174,6 +188,26 @@ def _slot_worker(rank, world, port, out):
     early_ok = early_ok and bool((mod3.w == 3.0).all()) and eng2.store.refreshed == 1 and eng2.packed == 1 \
         and eng2.fp8._w_ready is False and cb3._sync is not None
     cb_ok = cb_ok and early_ok
+    # overlapped exchange on the Lightning surface: the autograd bridge brackets the engine's backward, the buckets go out
+    # between its segments, d loss (0.5 here) and 1 / world are applied to the SUM afterwards
+    from maestro_amd.train.model import _EngineLoss
+    eng4 = _FakeEngine(n, rank)
+    eng4.store.params, eng4.store.fresh = [], True
+    cb4 = EngineDDPCallback(bucket_mb=1, overlap=True)
+    cb4.bucket_bytes = 4 * 300
+    mod4 = SimpleNamespace(model=SimpleNamespace(_engine=None, _sup_engine=None))
+    cb4.on_train_batch_start(None, mod4, None, 0)          # step 0: the engine does not exist yet
+    mod4.model._engine = eng4                               # ... training_step builds it
+    loss = _EngineLoss.apply(torch.zeros((), requires_grad=True), eng4, eng4.loss_acc)
+    cb4.on_before_backward(None, mod4, loss)
+    (loss * 0.5).backward()
+    cb4.on_after_backward(None, mod4)                       # must NOT exchange a second time
+    want4 = torch.arange(n, dtype=torch.float32) * 1.5 * 0.5
+    ovl_ok = (eng4.grad_exchange is cb4 and torch.equal(eng4.store.grad, want4)
+              and eng4.in_flight[0] == [(600, n + 64)]      # first bucket (with the loss slot) in flight after the first segment
+              and eng4.in_flight[1] == [(600, n + 64), (250, 600)]
+              and abs(float(cb4.loss_mean) - 15.0) < 1e-6 and not cb4._exchanged_in_backward)
+    cb_ok = cb_ok and ovl_ok
     met = MeanMetric()
     met.update(torch.tensor(float(rank + 1)))
     met.update(3.0 * (rank + 1))

@@ -215,3 +215,99 @@ def test_full_plan_two_ranks_equal_the_concatenated_batch(bucket_dtype):
     assert upd_single.abs().max().item() > 0 and rel < 2e-2, f"update of the 2-rank run differs from the large-batch run: rel L2 {rel:.3e}"
     for a, b0, b1 in zip(single_losses, res[0][4], res[1][4]):
         assert abs(a - 0.5 * (b0 + b1)) < 2e-3 * abs(a), (a, b0, b1)     # mean of the ranks' losses = the large batch's loss
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The same exchange on the LIGHTNING surface (SSLModule.training_step -> loss.backward() -> torch optimizer, with
+# EngineDDPCallback's hooks called in Lightning's order): overlapped buckets inside the backward (default) against the single
+# exchange after it, with two accumulated micro-batches in the last step (d loss = 1/2 from the trainer).
+def _lightning_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+
+    import maestro_amd.conf as conf
+    from maestro_amd.train.ddp import EngineDDPCallback
+    from maestro_amd.train.model import SSLModule
+    from maestro_amd.train.trainer import synthetic_batch
+    dev = torch.device("cuda:0")
+    ds = conf.DatasetsConfig(name_dataset="treesatai_ts", treesatai_ts=conf.TreeSatAITSConfig(
+        filter_inputs=["aerial", "s2"], filter_targets=[],
+        aerial=conf.InputRasterConfig(image_size=60, patch_size=conf.PatchSizeConfig(mae=20), bands=4, norm_bands=[1, 3], norm_fac=255.0)))
+    res = {}
+    for overlap in (False, True):
+        torch.manual_seed(rank)        # DIFFERENT initial weights per rank: on_fit_start must bring rank 0's everywhere
+        mod = SSLModule(datasets=ds, mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=1,
+                        model="mae", model_size="tiny", loss="l2_norm", use_ema=False)
+        mod.trainer = SimpleNamespace(ssl_phase="pretrain", train_dataloader=SimpleNamespace(batch_size=2),
+                                      accumulate_grad_batches=1, num_nodes=1, num_devices=world, base_lr=3e-3, wd=0.01, b1=0.9,
+                                      b2=0.99, final_factor=1e7, estimated_stepping_batches=20, max_epochs=5)
+        cb = EngineDDPCallback(bucket_mb=1, overlap=overlap)
+        cb.on_fit_start(mod.trainer, mod)
+        opt = mod.configure_optimizers()["optimizer"]
+        batches = [synthetic_batch(ds.dataset, 2, dev, seed=10 * rank + i) for i in range(2)]
+        torch.manual_seed(100 + rank)  # different masks per rank, the same in both modes
+        grads, n_buckets = [], []
+        for step, micro in enumerate(([0], [1], [0, 1])):
+            opt.zero_grad(set_to_none=True)
+            for i in micro:
+                cb.on_train_batch_start(mod.trainer, mod, batches[i], step)
+                loss = mod.training_step(batches[i], step)["loss"] / len(micro)
+                cb.on_before_backward(mod.trainer, mod, loss)
+                loss.backward()
+                cb.on_after_backward(mod.trainer, mod)
+                n_buckets.append(len(cb._sync.launched))
+            torch.cuda.synchronize()
+            grads.append(mod.model._engine.store.grad.cpu().numpy().copy())
+            opt.step()
+        torch.cuda.synchronize()
+        eng = mod.model._engine
+        flat = torch.cat([p.detach().reshape(-1) for p in eng.store.params]).cpu()
+        allp = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(allp, flat)
+        res[overlap] = (all(torch.equal(allp[0], p) for p in allp), flat.numpy(), grads, n_buckets,
+                        sorted(k for k in eng._graphs if k.startswith("bwd")))
+    out.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_lightning_surface_overlapped_exchange_two_ranks():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 31900 + os.getpid() % 1000
+    procs = [ctx.Process(target=_lightning_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        for _ in range(180):
+            try:
+                rank, item = out.get(timeout=1)
+                res[rank] = item
+                break
+            except queue.Empty:
+                assert all(p.exitcode in (None, 0) for p in procs), "a rank crashed"
+        else:
+            raise AssertionError("ranks did not report within 180 s")
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        for overlap in (False, True):
+            same, flat, grads, n_buckets, graphs = res[rank][overlap]
+            assert same, f"rank {rank}, overlap={overlap}: parameters differ between the ranks"
+            assert np.isfinite(flat).all() and all(np.abs(g).max() > 0 for g in grads)
+        plain, ovl = res[rank][False], res[rank][True]
+        assert all(n >= 2 for n in ovl[3]), f"overlap mode should launch several buckets per backward: {ovl[3]}"
+        assert any(k.endswith(":h") for k in ovl[4]) and not any(k.endswith(":h") for k in plain[4]), (ovl[4], plain[4])
+        for step, (g0, g1) in enumerate(zip(plain[2], ovl[2])):   # (same masks, same weights up to the plans' summation order)
+            rel = np.linalg.norm(g0 - g1) / np.linalg.norm(g0)
+            assert rel < 1e-3, f"rank {rank} step {step}: overlapped exchange changes the averaged gradient (rel {rel:.2e})"
+        upd = np.linalg.norm(plain[1] - ovl[1]) / np.linalg.norm(plain[1])
+        assert upd < 1e-3, upd
+    for overlap in (False, True):
+        assert np.array_equal(res[0][overlap][1], res[1][overlap][1])
