@@ -12,8 +12,10 @@ definition, anchored on the reference's call sites (``maestro/ssl/mae.py:135-141
 
 State-dict sub-keys therefore are ``layers.<l>.0.{norm,to_qkv,to_out.0}``, ``layers.<l>.1.net.{0,1,4}``, ``norm``.
 Dropout is 0 everywhere at the call sites, so it is omitted from the arithmetic (modules kept for key parity).
-"parity unpinned" by the reference (its tests never run a forward); pinned here by ``transformer_fp64``,
-an independent loop-level float64 restatement of the same equations (tests/test_oracle_vit.py).
+"parity unpinned" by the reference (its tests never run a forward); pinned here (tests/test_oracle_vit.py) by
+``transformer_fp64``, an independent loop-level float64 restatement of the same equations, and by code that was NOT written
+in this repo: ``torch.nn.TransformerEncoder(norm_first=True, activation="gelu")`` -- the torch library's implementation of the
+same published pre-LN block -- reproduces this module's outputs and gradients to 1e-10 under the key map in that test.
 """
 
 from __future__ import annotations
