@@ -24,9 +24,9 @@ def short(name):
     """rocprof kernel name -> the label maestro_amd.hip.KernelTimer / bench.py use for the same kernel."""
     import re
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"gemm_kernel<(\w+), (\w+)>", name)
+    m = re.match(r"gemm_kernel<(\w+), (\w+)(?:, (\d+))?>", name)     # (+ the tile height in 32-row units since round 3)
     if m:
-        return f"gemm_kernel<{_LAYOUT[m.groups()]}>"
+        return f"gemm_kernel<{_LAYOUT[m.groups()[:2]]}{ {'2': ',64x128', '6': ',192x128'}.get(m.group(3), '') }>"
     m = re.match(r"gemm_dma_kernel<Tile<([\d, ]+)>, (\w+), (\w+)(?:, \w+)?>", name)   # (+ the STAGGER flag since round 2)
     if m:
         return f"gemm_dma_kernel<{_TILE[m.group(1)]},{_LAYOUT[(m.group(2), m.group(3))]}>"
