@@ -7,6 +7,7 @@ hot path lives in the HIP kernels.  References: ``maestro/layers/utils.py:103-12
 
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.nn.functional as F  # noqa: N812
 from torch import Tensor
@@ -43,30 +44,32 @@ def draw_struct_masks(groups, mods, generator=None) -> dict[str, Tensor]:
     rejection-loop iteration = modalities in ``dataset.inputs`` order, each: mod, bands, dates, loc (only the active
     ones) -- exactly the reference's order so that a fixed seed gives bit-identical masks on the CPU generator.
     """
-    done = {g.name: None for g in groups}
-    pending = {g.name: torch.ones(g.Beff, dtype=torch.bool) for g in groups}
-    out = {g.name: torch.ones(g.Beff, g.L, dtype=torch.bool) for g in groups}
-    while any(bool(p.any()) for p in pending.values()):
+    # The random numbers come from torch (the reference's generator and draw order); the boolean bookkeeping around them runs
+    # in numpy: these arrays are a few KiB, and torch's reductions over them go through the intra-op thread pool -- with the
+    # default pool of a many-core host inside a container that may schedule a fraction of those cores, ONE ``.all(dim=1)`` was
+    # measured at 6 ms (12 ms per step: more than half of the GPU's step time, spent on the host before the first launch).
+    pending = {g.name: np.ones(g.Beff, dtype=bool) for g in groups}
+    out = {g.name: np.ones((g.Beff, g.L), dtype=bool) for g in groups}
+    while any(p.any() for p in pending.values()):
         draw = {}
         for m in mods.values():
             if m.gi:                     # band-groups 1.. of a modality: drawn together with its group 0
                 continue
             B, D, L, G = m.Beff, m.D, m.L, m.G  # noqa: N806
-            mk = torch.zeros(B, G, D, L, dtype=torch.bool)
+            mk = np.zeros((B, G, D, L), dtype=bool)
             if m.p_mod:
-                mk = mk | (torch.rand((B, 1, 1, 1), generator=generator) < m.p_mod)
+                mk = mk | (torch.rand((B, 1, 1, 1), generator=generator) < m.p_mod).numpy()
             if m.p_bands:
-                mk = mk | (torch.rand((B, G, 1, 1), generator=generator) < m.p_bands)
+                mk = mk | (torch.rand((B, G, 1, 1), generator=generator) < m.p_bands).numpy()
             if m.p_dates:
-                mk = mk | (torch.rand((B, 1, D, 1), generator=generator) < m.p_dates)
+                mk = mk | (torch.rand((B, 1, D, 1), generator=generator) < m.p_dates).numpy()
             if m.p_loc:
-                mk = mk | (torch.rand((B, 1, 1, L), generator=generator) < m.p_loc)
+                mk = mk | (torch.rand((B, 1, 1, L), generator=generator) < m.p_loc).numpy()
             for gi in range(G):          # the specs of one modality are named <modality>#<g> when there are several
                 draw[m.name if G == 1 else f"{m.src}#{gi}"] = mk[:, gi].reshape(B, D * L)
         for g in groups:
-            new = torch.cat([draw[m.name] for m in g.mods], dim=1)
+            new = np.concatenate([draw[m.name] for m in g.mods], axis=1)
             take = pending[g.name]
-            out[g.name] = torch.where(take[:, None], new, out[g.name])
-            pending[g.name] = out[g.name].all(dim=1)
-    del done
-    return out
+            out[g.name] = np.where(take[:, None], new, out[g.name])
+            pending[g.name] = out[g.name].all(axis=1)
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in out.items()}
