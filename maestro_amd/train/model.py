@@ -288,7 +288,11 @@ class SSLModule(_Base):
         total_batch = tr.train_dataloader.batch_size * tr.accumulate_grad_batches * tr.num_nodes * tr.num_devices / 3.0
         lr = tr.base_lr * total_batch**0.5
         params = [p for n, p in self.named_parameters() if n != "_anchor"]
-        optimizer = torch.optim.AdamW(params, lr=lr, weight_decay=tr.wd, betas=(tr.b1, tr.b2))
+        # a torch.optim.AdamW (state-dict compatible with the reference's) whose step is one fused launch over the engine's
+        # flat buffer once an engine owns the parameters (maestro_amd/train/optim.py:EngineAdamW)
+        from maestro_amd.train.optim import EngineAdamW
+        optimizer = EngineAdamW(params, lambda: getattr(self.model, "_engine", None) or getattr(self.model, "_sup_engine", None),
+                                lr=lr, weight_decay=tr.wd, betas=(tr.b1, tr.b2))
         scheduler = torch.optim.lr_scheduler.OneCycleLR(
             optimizer, max_lr=lr, total_steps=tr.estimated_stepping_batches, pct_start=0.2, cycle_momentum=False,
             div_factor=1000, final_div_factor=tr.final_factor / 1000.0)

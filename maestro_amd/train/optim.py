@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import math
 
+import torch
+
 from maestro_amd import hip
 
 
@@ -93,3 +95,94 @@ class FusedAdamW:
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.t, self.lr = sd["t"], sd["lr"]
+
+
+class EngineAdamW(torch.optim.AdamW):
+    """The optimizer ``SSLModule.configure_optimizers`` hands to Lightning: a ``torch.optim.AdamW`` (same constructor, same
+    ``param_groups`` for ``OneCycleLR``, same ``state_dict`` layout -- ``state[p] = {step, exp_avg, exp_avg_sq}`` -- so optimizer
+    states interchange with the reference's checkpoints, ``maestro/train/model.py:135-140``) whose ``step()`` is ONE ``mh_adamw``
+    launch over the engine's flat buffer instead of torch's multi-tensor loop: the moments of all parameters live in two flat
+    buffers in the engine's layout (``state[p]`` holds VIEWS of them), the bf16 weight shadows are refreshed by the same pass.
+    Measured on C3, B = 32, Lightning-style step: torch's foreach AdamW 15 ms of host time and 1479 tiles/s -> see
+    ``profiles/README.md``.
+
+    ``engine_of()`` returns the engine that owns the parameters right now (or None before the first ``training_step``).  The
+    fused launch is used when the optimizer has ONE parameter group (the reference's case) with plain AdamW options and covers
+    every parameter of the engine's trainable span; otherwise ``torch.optim.AdamW.step`` runs unchanged."""
+
+    def __init__(self, params, engine_of, **kw) -> None:
+        super().__init__(params, **kw)
+        self._engine_of, self._bound, self._fused = engine_of, None, None
+
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)
+        self._bound = None            # the loaded moments are fresh tensors: adopt them into the flat buffers at the next step
+
+    def state_dict(self) -> dict:
+        """torch's layout.  Internally every parameter's ``step`` is ONE shared tensor (the fused launch has one step count);
+        a checkpoint must not carry that sharing -- ``torch.save`` preserves tensor identity, and torch's multi-tensor AdamW
+        increments every parameter's ``step`` tensor: a shared one would advance by the number of parameters per step in the
+        optimizer that loads it -- so each parameter gets its own copy here."""
+        sd = super().state_dict()
+        sd["state"] = {k: {n: (t.clone() if n == "step" and isinstance(t, torch.Tensor) else t) for n, t in v.items()}
+                       for k, v in sd["state"].items()}
+        return sd
+
+    def _eligible(self, eng) -> bool:
+        if eng is None or len(self.param_groups) != 1:
+            return False
+        g = self.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable") or isinstance(g["lr"], torch.Tensor):
+            return False
+        mine = {id(p) for p in g["params"]}
+        st = eng.store
+        lo, hi = getattr(eng, "trainable_span", (0, st.total))
+        span = [p for p in st.params if lo <= st.offset[id(p)] < hi]
+        if not all(id(p) in mine for p in span) or getattr(st, "fresh", True):
+            return False
+        # every gradient of the span must BE the flat buffer's slice (the autograd bridge attaches them)
+        return all(p.grad is not None and p.grad.data_ptr() == st.g(p).data_ptr() for p in span)
+
+    def _bind(self, eng) -> None:
+        """Moments into the engine's layout (adopting whatever per-parameter state exists: a loaded checkpoint, steps done by
+        torch's implementation, a previous engine of another batch size) and ``state[p]`` re-pointed at views of them."""
+        g = self.param_groups[0]
+        fused = FusedAdamW(eng, g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"])
+        st, lo, hi = eng.store, fused.lo, fused.hi
+        t = 0
+        with torch.no_grad():
+            for p in st.params:
+                o = st.offset[id(p)]
+                if not lo <= o < hi:
+                    continue
+                mv = fused.m[o - lo: o - lo + p.numel()].view(p.shape)
+                vv = fused.v[o - lo: o - lo + p.numel()].view(p.shape)
+                old = self.state.get(p)
+                if old and "exp_avg" in old:
+                    mv.copy_(old["exp_avg"])
+                    vv.copy_(old["exp_avg_sq"])
+                    t = max(t, int(float(old["step"])))
+                self.state[p] = {"exp_avg": mv, "exp_avg_sq": vv}
+            self._step = torch.tensor(float(t))      # ONE step counter shared by every parameter's state (torch: one each)
+            for p in st.params:
+                if p in self.state and "step" not in self.state[p]:
+                    self.state[p]["step"] = self._step
+        fused.t = t
+        self._fused, self._bound = fused, eng
+
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:        # Lightning's automatic optimization runs training_step + backward in here
+            with torch.enable_grad():
+                loss = closure()
+        eng = self._engine_of()
+        if not self._eligible(eng):
+            super().step()
+            return loss
+        if self._bound is not eng:
+            self._bind(eng)
+        g, f = self.param_groups[0], self._fused
+        f.betas, f.eps, f.wd = g["betas"], g["eps"], g["weight_decay"]
+        f.step(lr=float(g["lr"]))
+        self._step.fill_(float(f.t))
+        return loss

@@ -587,3 +587,131 @@ def test_band_groups_under_the_exchange_plan(golden_dir, name):
             assert covered[0][0] == 0 and covered[-1][1] == loop.engine.store.grad_all.numel()
             assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), covered
     assert all(abs(a - b) < 1e-3 * abs(a) for a, b in zip(*runs)), runs
+
+
+def test_engine_adamw_equals_torch_adamw_and_interchanges_state(golden_dir):
+    """``configure_optimizers`` returns ``EngineAdamW``: a ``torch.optim.AdamW`` whose step is one fused launch over the flat buffer.
+    Same trajectory as torch's own implementation on the Lightning-style loop (same masks every step), and its ``state_dict``
+    loads into a plain ``torch.optim.AdamW`` (the reference's optimizer, ``maestro/train/model.py:135-140``) and back."""
+    from types import SimpleNamespace
+
+    from maestro_amd.train.model import SSLModule
+    from maestro_amd.train.optim import EngineAdamW
+    from maestro_amd.train.trainer import synthetic_batch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    ds = conf.DatasetsConfig(name_dataset="treesatai_ts", treesatai_ts=conf.TreeSatAITSConfig(
+        filter_targets=[], aerial=conf.InputRasterConfig(image_size=60, patch_size=conf.PatchSizeConfig(mae=20), bands=4,
+                                                         norm_bands=[1, 3], norm_fac=255.0)))
+    batch = synthetic_batch(ds.dataset, 2, dev)
+
+    def build():
+        torch.manual_seed(0)
+        mod = SSLModule(datasets=ds, mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=3,
+                        model="mae", model_size="tiny", loss="l2_norm", use_ema=False)
+        mod.trainer = SimpleNamespace(ssl_phase="pretrain", train_dataloader=SimpleNamespace(batch_size=2),
+                                      accumulate_grad_batches=1, num_nodes=1, num_devices=1, base_lr=3e-3, wd=0.01, b1=0.9, b2=0.99,
+                                      final_factor=1e7, estimated_stepping_batches=20, max_epochs=5)
+        return mod
+
+    def run(mod, opt, sched, steps, first=0):
+        for step in range(first, first + steps):
+            torch.manual_seed(11 + step)
+            out = mod.training_step(batch, step)
+            opt.zero_grad(set_to_none=True)
+            out["loss"].backward()
+            opt.step()
+            sched.step()
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().reshape(-1) for _, p in sorted(mod.named_parameters()) if p.numel() > 1]).cpu()
+
+    def sched_of(opt, mod):  # noqa: ARG001
+        return torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=max_lr, total_steps=20, pct_start=0.2,
+                                                   cycle_momentum=False, div_factor=1000, final_div_factor=1e4)
+
+    # (a) fused step against torch's own AdamW, 4 steps
+    mod_a = build()
+    cfg = mod_a.configure_optimizers()
+    opt_a, sched_a = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+    max_lr = opt_a.defaults["lr"]
+    assert isinstance(opt_a, EngineAdamW) and isinstance(opt_a, torch.optim.AdamW)
+    init = torch.cat([p.detach().reshape(-1) for _, p in sorted(mod_a.named_parameters()) if p.numel() > 1]).cpu().clone()
+    # step by step against torch.optim.AdamW fed the SAME gradients and the same weights (deterministic comparison)
+    params_a = [p for n, p in mod_a.named_parameters() if n != "_anchor"]
+    twins = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in params_a]   # (the engine moves the trained parameters to the GPU)
+    opt_t = torch.optim.AdamW(twins, lr=opt_a.defaults["lr"], weight_decay=0.01, betas=(0.9, 0.99))
+    sched_t = sched_of(opt_t, None)
+    for step in range(4):
+        torch.manual_seed(11 + step)
+        out = mod_a.training_step(batch, step)
+        opt_a.zero_grad(set_to_none=True)
+        out["loss"].backward()
+        for t, p in zip(twins, params_a):
+            t.data.copy_(p.detach())
+            t.grad = None if p.grad is None else p.grad.detach().clone().to(dev)
+        opt_a.step()
+        sched_a.step()
+        opt_t.step()
+        sched_t.step()
+        worst = max(((p.detach().to(dev) - t.detach()).abs().max() / t.detach().abs().max().clamp(min=1e-3)).item() for t, p in zip(twins, params_a))
+        assert worst < 2e-6, (step, worst)
+    torch.cuda.synchronize()
+    got = torch.cat([p.detach().reshape(-1) for _, p in sorted(mod_a.named_parameters()) if p.numel() > 1]).cpu()
+    assert opt_a._fused is not None and opt_a._fused.t == 4, "the fused launch was not used"
+    mod_b = build()
+    params_b = [p for n, p in mod_b.named_parameters() if n != "_anchor"]
+    opt_b = torch.optim.AdamW(params_b, lr=opt_a.defaults["lr"], weight_decay=0.01, betas=(0.9, 0.99))
+    sched_b = sched_of(opt_b, mod_b)
+    want = run(mod_b, opt_b, sched_b, 4)
+    upd_got, upd_want = got - init, want - init
+    rel = ((upd_got - upd_want).norm() / upd_want.norm()).item()
+    # (two separate RUNS: the early AdamW updates are ~ lr * sign(g), so the atomics' summation order shows at the 1e-3 level)
+    assert upd_want.abs().max() > 0 and rel < 2e-2, rel
+    # (b) state interchange, again step by step on identical gradients:
+    #     torch.optim.AdamW's state -> EngineAdamW (adopted into the flat moment buffers at the next step) ...
+    def lockstep(opt_fused, sched_fused, opt_torch, sched_torch, first, steps):
+        for step in range(first, first + steps):
+            torch.manual_seed(11 + step)
+            out = mod_a.training_step(batch, step)
+            opt_fused.zero_grad(set_to_none=True)
+            out["loss"].backward()
+            for t, p in zip(twins, params_a):
+                t.data.copy_(p.detach())
+                t.grad = None if p.grad is None else p.grad.detach().clone().to(dev)
+            opt_fused.step()
+            sched_fused.step()
+            opt_torch.step()
+            sched_torch.step()
+            worst = max(((p.detach().to(dev) - t.detach()).abs().max() / t.detach().abs().max().clamp(min=1e-3)).item()
+                        for t, p in zip(twins, params_a))
+            assert worst < 2e-6, (step, worst)
+
+    import io
+
+    def through_a_file(sd):          # (load_state_dict aliases the tensors it is given: interchange goes through a checkpoint file)
+        buf = io.BytesIO()
+        torch.save(sd, buf)
+        buf.seek(0)
+        return torch.load(buf, weights_only=False)
+
+    sd_b = opt_b.state_dict()
+    assert set(sd_b["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    opt_a.load_state_dict(through_a_file(sd_b))
+    opt_t.load_state_dict(through_a_file(sd_b))
+    assert opt_a._bound is None
+    lockstep(opt_a, sched_a, opt_t, sched_t, 4, 2)
+    assert opt_a._fused.t == 6 and float(opt_a.state[params_a[0]]["step"]) == 6.0
+    #     ... and EngineAdamW's state -> a fresh torch.optim.AdamW (what the reference would load from our checkpoint)
+    sd_a = opt_a.state_dict()
+    assert set(sd_a["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd_a["state"][0]["step"]) == 6.0
+    assert len(sd_a["state"]) == len(sd_b["state"])          # the same parameters carry state (those that received gradients)
+    opt_f = torch.optim.AdamW(twins, lr=opt_a.defaults["lr"], weight_decay=0.01, betas=(0.9, 0.99))
+    opt_f.load_state_dict(through_a_file(sd_a))
+    sched_f = sched_of(opt_f, None)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")     # ("scheduler stepped before the optimizer": it is being restored to position 6)
+        sched_f.last_epoch = 5
+        sched_f.step()
+    lockstep(opt_a, sched_a, opt_f, sched_f, 6, 2)
