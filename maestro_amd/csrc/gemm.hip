@@ -262,7 +262,17 @@ extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, cons
         const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
         if (t128 > 512 && t128 <= 576 && (long)ceil_div(M, 192) * ceil_div(N, 128) <= 512) tile = MH_TILE_REG_192;
     }
-    if (tile == MH_TILE_AUTO && !(flags & MH_GEMM_MULAUX) && (!dma || (layout == 0 && K < 1024))) {
+    // Round 3, second pass -- the rule below follows the kernels' times INSIDE the step (bench.py --shapes on the pretrain, probe and
+    // finetune steps, profiles/README.md), which differ from the isolated loops above (operands are cold, the fp32 residual is
+    // read, two group streams share the chip): the ping-pong tile keeps the NT problems between one round of workgroups and
+    // 8192 tiles (qkv +6 %, out-proj +11 %, fc2 +4 % at M = 32768; +2 ... 5 % at M = 8192), loses the fc1 (GELU) epilogue beyond
+    // ~2300 tiles (M = 32768: -7 % against the LDS-DMA tile, M = 12800: -2 %), loses 27 % on the segmentation head (M = 557056,
+    // 52224 tiles, 1.7 GB of output: the LDS-DMA tile's staged full-line stores), and is a tie or a loss on every NN (dgrad)
+    // problem in the step (M = 3200: -9 %), so those stay with the one-tile-per-workgroup / LDS-DMA kernels.
+    const long t128_all = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    const bool pp_ok = layout == 0 && t128_all >= 256 &&
+                       ((flags & MH_GEMM_GELU) ? t128_all <= 2304 : (!dma || (K < 1024 && t128_all <= 8192)));
+    if (tile == MH_TILE_AUTO && !(flags & MH_GEMM_MULAUX) && pp_ok) {
         const int rc = gemm_pp_dispatch(layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, stream);
         if (rc != -2) return rc;   // -2: not eligible -> the kernels below
     }

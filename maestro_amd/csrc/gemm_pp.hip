@@ -361,7 +361,13 @@ int gemm_pp_dispatch(int layout, int M, int N, int K, const void* A, int lda, co
     if (a_reach >= lim || b_reach >= lim || c_reach >= lim || x_reach >= lim) return -2;
     p.a_bytes = (unsigned)a_ext; p.b_bytes = (unsigned)b_ext;
     const int tiles = p.tiles_m * p.tiles_n;
-    const int grid = tiles >= 512 ? 512 : (tiles + 7) / 8 * 8;   // two workgroups per CU; a multiple of 8 (XCD runs)
+    // MH_PP_TILES_PER_WG (build time): 0 = fully persistent (512 workgroups walk all tiles); n > 0: a workgroup walks at most n tiles
+    // (shorter-lived workgroups let the dispatcher interleave another stream's kernel sooner, at one exposed epilogue per n tiles)
+#ifndef MH_PP_TILES_PER_WG
+#define MH_PP_TILES_PER_WG 0
+#endif
+    int grid = tiles >= 512 ? 512 : (tiles + 7) / 8 * 8;   // two workgroups per CU; a multiple of 8 (XCD runs)
+    if (MH_PP_TILES_PER_WG > 0) grid = max(grid, ((tiles + MH_PP_TILES_PER_WG - 1) / MH_PP_TILES_PER_WG + 7) / 8 * 8);
     if (b_kmajor) launch_pp<true>(epi, grid, p, (hipStream_t)stream);
     else launch_pp<false>(epi, grid, p, (hipStream_t)stream, diag);
     MH_LAUNCH_CHECK();

@@ -155,7 +155,12 @@ def _uses_pp(layout, M, N, K, flags) -> bool:  # noqa: N803
     served = flags in (0, BIAS | GELU | AUX_DGELU | AUX_U8, OUT_F32 | BIAS | RESIDUAL)
     if not served or layout == GEMM_TN or K % 64 or K < 512 or N % 128 or _uses_192(layout, M, N, K, flags):
         return False
-    return not _uses_dma(layout, M, N, K, flags) or (layout == GEMM_NT and K < 1024)
+    t128 = -(-M // 128) * -(-N // 128)
+    if layout != GEMM_NT or t128 < 256:
+        return False
+    if flags & GELU:
+        return t128 <= 2304
+    return not _uses_dma(layout, M, N, K, flags) or (K < 1024 and t128 <= 8192)
 
 
 def _auto_tile_name(layout, M, N, K, flags) -> int:  # noqa: N803

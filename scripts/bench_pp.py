@@ -17,8 +17,9 @@ FC1 = hip.BIAS | hip.GELU | hip.AUX_DGELU | hip.AUX_U8
 DFC2 = hip.MULAUX | hip.AUX_U8 | hip.COLSUM
 F32 = hip.OUT_F32 | hip.BIAS | hip.RESIDUAL
 cases = []
-for M in (8192, 11392, 3200, 12800, 32768):
-    dim, mlp, inner = (768, 3072, 768) if M in (8192, 11392, 3200) else (512, 3072, 512)
+SUP = os.environ.get("PP_SHAPES", "") == "sup"      # the probe / finetune step: UNMASKED encoder sequences (B = 32: 32768 + 12800, joint 45568 rows)
+for M in ((32768, 12800, 45568) if SUP else (8192, 11392, 3200, 12800, 32768)):
+    dim, mlp, inner = (768, 3072, 768) if (SUP or M in (8192, 11392, 3200)) else (512, 3072, 512)
     cases += [("qkv", 0, M, 3 * inner, dim, 0), ("fc1", 0, M, mlp, dim, FC1), ("out", 0, M, dim, inner, F32), ("fc2", 0, M, dim, mlp, F32),
               ("dfc2", 1, M, mlp, dim, DFC2), ("dfc1", 1, M, dim, mlp, 0), ("dqkv", 1, M, dim, 3 * inner, 0)]
 only = sys.argv[1:]
@@ -34,6 +35,8 @@ for name, lay, M, N, K, fl in cases:
     kw = dict(bias=bias if fl & hip.BIAS else None, res=res, ldr=N if res is not None else 0, ldaux=N if aux is not None else 0,
               aux_out=aux if fl & hip.AUX_DGELU else None, aux_in=aux if fl & hip.MULAUX else None, colsum=cs)
     variants = {"reg128": hip.TILE_REG_128, "pp128": hip.TILE_PP_128, "auto": hip.TILE_AUTO, "reg64": hip.TILE_REG_64, "reg192": hip.TILE_REG_192}
+    if SUP:
+        variants = {"reg128": hip.TILE_REG_128, "pp128": hip.TILE_PP_128, "d256": hip.TILE_DMA_256, "auto": hip.TILE_AUTO, "reg192": hip.TILE_REG_192}
     res_t = {k: [] for k in variants}
     ok = {}
     for k, t in variants.items():
