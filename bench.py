@@ -416,7 +416,7 @@ def main() -> None:
             # launches move 30-100 MB in 8-25 us: the launch ramp alone (~2 us) caps them well below a long stream's rate.
             out["hbm_substages"] = timer.hbm_substages(HBM_PEAK_TBS * 1e3)
         if timer is not None and args.shapes:
-            for ms, kind, shape, n, tf in timer.by_shape(args.steps)[:40]:
+            for ms, kind, shape, n, tf in timer.by_shape(args.steps)[:80]:
                 print(f"{ms:8.3f} ms/step {kind:18s} {str(shape):26s} x{n:3d}/step {tf:7.1f} TFLOP/s", file=sys.stderr)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds, args.phase)

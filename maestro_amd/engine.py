@@ -549,6 +549,18 @@ class EngineBase:
         # Off by default: on C3 the isolated timings pick tiles that are 1 % slower inside the two-stream step than the
         # library's own rule (1291 vs 1303 tiles/s, same box).
         self.tune_gemm = os.environ.get("MAESTRO_TUNE", "0") == "1"
+        # MAESTRO_INSTEP_TUNE=1 (opt-in): the FIRST step is run several times with the same inputs and draws -- eagerly, on one
+        # stream, one candidate GEMM tile per pass -- and every GEMM signature keeps the tile that was fastest between the step's
+        # own kernels when it beats the library's rule by 3 % (hip.InStepTuner).  One optimizer update per step as always: the
+        # passes only recompute the same forward / backward.  Not with fp8 (the delayed scaling state would advance), an optimizer
+        # overlapped into the forward, or when a tile is forced by the environment.  Measured and NOT the default: on C3 the
+        # tuned table is 0.5 % faster in the eager single-stream sum of GEMM times and 0.7 % SLOWER in the real step (1716 vs 1726
+        # tiles/s, same box) -- like the isolated ranking before it, per-launch times on one stream do not rank tiles for the
+        # two-stream, graph-replayed step within the few per cent that separate them; the static rule in gemm.hip was fitted to
+        # whole-step A/B runs instead.
+        self.instep_tune = (os.environ.get("MAESTRO_INSTEP_TUNE", "0") == "1" and not self.tune_gemm
+                            and not any(os.environ.get(k) for k in ("MH_GEMM_TILE", "MH_GEMM_DMA", "MH_GEMM_PP", "MH_DMA_STAGGER")))
+        self.tile_report = None     # {signature: (picked tile, {candidate: ms})} of this engine's tuning passes
         # the GELU derivative saved by the fc1 epilogue for the backward: one byte per element (MH_GEMM_AUX_U8, step 0.005 on
         # [-0.129, 1.129]) instead of bf16 -- 1.7 GB less HBM traffic per C3 step; MAESTRO_AUX_U8=0 keeps bf16
         self.aux_flag = hip.AUX_U8 if os.environ.get("MAESTRO_AUX_U8", "1") == "1" else 0
@@ -610,6 +622,27 @@ class EngineBase:
                 fn()
         for side in sides:
             main.wait_stream(side)
+
+    def _instep_tune(self, one_pass) -> None:
+        """``one_pass()``: forward + zero_grad + backward of the current step (same inputs, same draws)."""
+        self.instep_tune = False
+        if (getattr(self, "fp8", None) is not None or getattr(self, "_opt", None) is not None or hip.kernel_timer_active()
+                or torch.cuda.is_current_stream_capturing()):
+            return
+        saved = (self.use_graphs, self.multi_stream, self.grad_hook)
+        self.use_graphs, self.multi_stream, self.grad_hook = False, False, None
+        tuner = hip.InStepTuner()
+        hip.set_instep_tuner(tuner)
+        try:
+            one_pass()                                  # untimed: first-use allocations, lazily built tables
+            for cand in tuner.CANDIDATES:
+                tuner.begin(cand)
+                one_pass()
+            tuner.begin(None)
+            self.tile_report = tuner.finish()
+        finally:
+            hip.set_instep_tuner(None)
+            self.use_graphs, self.multi_stream, self.grad_hook = saved
 
     @contextlib.contextmanager
     def _tuning_pass(self, what: str):
@@ -903,6 +936,12 @@ class MAEEngine(EngineBase):
             n2, s2 = self.draw_masks()
             noise = noise if noise is not None else n2
             struct = struct if struct is not None else s2
+        if self.instep_tune:           # first step: pick the GEMM tiles between the step's own kernels (same inputs, same draws)
+            def one_pass():
+                self.forward(batch, noise=noise, struct=struct)
+                self.zero_grad()
+                self.backward()
+            self._instep_tune(one_pass)
         # host -> pinned ring slot -> device (outside any graph).  A slot is reused every RING steps; only then do we wait
         # for the async copies that last read it (the host may run several steps ahead of the GPU, but a per-step
         # hipEventSynchronize was measured to wake up ~10 ms late and starve the queue).

@@ -137,6 +137,12 @@ class SupervisedEngine(EngineBase):
         """Forward + ``loss_pred``; returns the loss as a 1-element device tensor (no host sync)."""
         if self.store.refresh_half():
             self._pack_conv_weights()
+        if self.instep_tune:           # first step: pick the GEMM tiles between the step's own kernels (engine.py:_instep_tune)
+            def one_pass():
+                self.forward(batch)
+                self.zero_grad()
+                self.backward()
+            self._instep_tune(one_pass)
         batch = dict(batch)
         sources = [parts[0] for parts in self.model.src_specs.values()]      # one spec per batch entry (band-group 0)
         for s in sources:

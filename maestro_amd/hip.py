@@ -85,6 +85,57 @@ def gemm_tile_choices() -> dict:
     return dict(_tile_choice)
 
 
+class InStepTuner:
+    """Picks, per GEMM signature of a step, the tile that is fastest INSIDE the step.
+
+    Round 3 finding (profiles/README.md): the fastest tile in an isolated loop (hot operands, nothing else on the chip) is often
+    not the fastest between the step's other kernels -- the isolated ranking cost the probe step 2.5 % -- while HIP-event times
+    of the step's own eager launches predicted the whole-step A/B.  So the engine runs its first step several times with the
+    same inputs and draws, one candidate tile per pass for every signature at once (``begin``), each launch bracketed by events on
+    its stream; ``finish`` keeps a candidate only where it beats the library's rule (MH_TILE_AUTO) by ``margin`` over all
+    launches of that signature, else the rule stays.  Choices land in the process-wide table ``_pick_tile`` consults."""
+
+    CANDIDATES = (TILE_AUTO, TILE_REG_128, TILE_PP_128, TILE_REG_64, TILE_REG_192, TILE_DMA_256)
+
+    def __init__(self) -> None:
+        self.cand, self.ev, self.bad = None, {}, set()
+
+    def begin(self, cand) -> None:
+        """``None``: launches run under the rule and are not timed (the warm-up pass)."""
+        self.cand = cand
+
+    def open(self, key):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.ev.setdefault(key, {}).setdefault(self.cand, []).append((e0, e1))
+        return e0, e1
+
+    def reject(self, key) -> None:
+        self.bad.add((key, self.cand))
+
+    def finish(self, margin: float = 0.03) -> dict:
+        torch.cuda.synchronize()
+        report = {}
+        for key, per in self.ev.items():
+            base_n = len(per.get(TILE_AUTO, ()))
+            ms = {c: sum(a.elapsed_time(b) for a, b in evs) for c, evs in per.items()
+                  if (key, c) not in self.bad and len(evs) == base_n and base_n}
+            if TILE_AUTO not in ms:
+                continue
+            best = min(ms, key=ms.get)
+            pick = best if ms[best] < (1.0 - margin) * ms[TILE_AUTO] else TILE_AUTO
+            _tile_choice[key] = pick
+            report[key] = (pick, ms)
+        return report
+
+
+_instep: InStepTuner | None = None
+
+
+def set_instep_tuner(t: InStepTuner | None) -> None:
+    global _instep
+    _instep = t
+
+
 def _gemm_tile(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum) -> int:  # noqa: N803
     return lib().mh_gemm_bf16_tile(_I(tile), _I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C),
                                    _I(ldc), _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux),
@@ -177,11 +228,24 @@ def gemm(layout: int, M: int, N: int, K: int, A, lda: int, B, ldb: int, C, ldc: 
     signature if there is one, else the library's own rule (MH_TILE_AUTO)."""
     args = (layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum)
     explicit = tile is not None
+    if _instep is not None and _instep.cand is not None and not explicit and not (flags & ATOMIC):
+        key = (layout, M, N, K, flags & ~COLSUM)
+        e0, e1 = _instep.open(key)
+        e0.record()
+        rc = _gemm_tile(_instep.cand, *args)
+        if rc == -2:                   # the candidate does not serve this problem: not a contender for this signature
+            _instep.reject(key)
+            rc = _gemm_tile(TILE_AUTO, *args)
+        _check(rc, "mh_gemm_bf16_tile")
+        e1.record()
+        return
     if not explicit:
         tile = _pick_tile(layout, M, N, K, flags, args)
     ev = None
     if _timer is not None:
         named = tile if tile != TILE_AUTO else _auto_tile_name(layout, M, N, K, flags)
+        if named in (TILE_REG_64, TILE_REG_192) and (layout == GEMM_TN or (flags & COLSUM)):
+            named = TILE_REG_128       # (the tile height applies to K-minor A without column sums; the library falls back silently)
         ev = _timer.record(_TILE_NAME[named].format(_LAYOUT_NAME[layout]), 2.0 * M * N * K, (M, N, K))
         ev[0].record()
     rc = _gemm_tile(tile, *args)
