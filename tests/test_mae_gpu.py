@@ -715,3 +715,46 @@ def test_engine_adamw_equals_torch_adamw_and_interchanges_state(golden_dir):
         sched_f.last_epoch = 5
         sched_f.step()
     lockstep(opt_a, sched_a, opt_f, sched_f, 6, 2)
+
+
+def test_instep_tile_tuner_keeps_the_step_intact(golden_dir):
+    """The opt-in first-step tuner (``MAESTRO_INSTEP_TUNE=1`` / ``engine.instep_tune``) recomputes the step once per candidate tile:
+    the result of the step is the one a plain engine gives (any tile computes the same GEMM), exactly one set of draws is used,
+    and every GEMM signature of the step got a decision."""
+    from maestro_amd import hip
+    dev, case, gold, ds, oracle, model, batch, noise, struct = _setup("c3_aerial_s2", golden_dir)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    eng = model.engine(case["B"], dev, loss="l2_norm")
+    eng.forward(dbatch, noise=noise, struct=struct)
+    eng.zero_grad()
+    eng.backward()
+    torch.cuda.synchronize()
+    want_loss, want_grad = eng.loss_acc.clone(), eng.store.grad.clone()
+    before = dict(hip.gemm_tile_choices())
+    try:
+        model._engine = None                      # a fresh engine on the same parameters
+        eng2 = model.engine(case["B"], dev, loss="l2_norm")
+        draws = []
+        inner = eng2.draw_masks
+        eng2.draw_masks = lambda *a, **k: draws.append(1) or inner(*a, **k)
+        eng2.instep_tune = True
+        eng2.forward(dbatch, noise=noise, struct=struct)
+        eng2.zero_grad()
+        eng2.backward()
+        torch.cuda.synchronize()
+        assert eng2.instep_tune is False and eng2.tile_report, "the tuning passes did not run"
+        assert not draws, "injected draws must be reused by every pass"
+        assert all(pick in hip.InStepTuner.CANDIDATES and hip.TILE_AUTO in ms for pick, ms in eng2.tile_report.values())
+        assert abs(eng2.loss_acc.item() - want_loss.item()) < 2e-3 * abs(want_loss.item())
+        rel = ((eng2.store.grad - want_grad).norm() / want_grad.norm()).item()
+        assert rel < 5e-3, rel                     # other tiles: the GELU differs by one bf16 ulp in a few elements
+        # a second step replays the captured graphs with the chosen tiles
+        for _ in range(2):
+            eng2.forward(dbatch, noise=noise, struct=struct)
+            eng2.zero_grad()
+            eng2.backward()
+        torch.cuda.synchronize()
+        assert ((eng2.store.grad - want_grad).norm() / want_grad.norm()).item() < 5e-3 and eng2._graphs
+    finally:
+        hip._tile_choice.clear()
+        hip._tile_choice.update(before)
