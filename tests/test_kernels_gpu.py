@@ -105,7 +105,8 @@ def test_attention_softmax_spike(dev):
 
 # ----------------------------------------------------------------------------------------------- patch embed
 @pytest.mark.parametrize("BD,C,S,P,norm_bands,elev", [(3, 4, 64, 16, (1, 3), False), (4, 10, 10, 2, (4, 4, 2), False),
-                                                       (2, 2, 64, 32, (2,), True), (2, 4, 100, 20, (1, 3), False),
+                                                       (2, 2, 64, 32, (2,), True), (2, 4, 100, 20, (1, 3), False), (2, 2, 64, 16, (2,), True), (2, 3, 48, 16, (3,), False),
+                                                       (1, 1, 32, 16, (1,), False),
                                                        (5, 2, 6, 2, (1, 1), False), (2, 3, 64, 8, (3,), False)])
 @pytest.mark.parametrize("normalise", [True, False])
 def test_patchify(dev, BD, C, S, P, norm_bands, elev, normalise):
@@ -317,16 +318,17 @@ def test_masked_loss(dev, p, B, Lm, Lg, off, PPC):
     assert (drec.float() - rec.grad).abs().max() < 1e-2 * scale
 
 
+@pytest.mark.parametrize("P", [8, 16])       # 16: the one-wave-per-patch kernel (channel windows, rescale against channel 0 of the raster)
 @pytest.mark.parametrize("elev", [False, True])
 @pytest.mark.parametrize("sizes", [(2, 2), (3, 1), (1, 1, 2)])
-def test_patchify_and_loss_over_band_groups(dev, sizes, elev):
+def test_patchify_and_loss_over_band_groups(dev, sizes, elev, P):  # noqa: N803
     """Several band-groups per modality (``mh_patchify_bands`` / ``mh_count_masked_elems`` / ``mh_masked_loss_bands``):
     every band-group's im2col rows are the window of the plain kernel's rows, the elevation rescale refers to channel 0 of the
     RASTER, and the modality's loss is ONE mean over the masked elements of all its band-groups, each group's reconstruction
     compared with its (strided) window of the modality-level target."""
     from maestro_amd import hip
     from oracle import layers as ol
-    BD, S, P, C = 3, 32, 8, sum(sizes)  # noqa: N806
+    BD, S, C = 3, 32, sum(sizes)  # noqa: N806
     g, PP = S // P, P * P  # noqa: N806
     T = BD * g * g  # noqa: N806
     img = torch.rand(BD, C, S, S, generator=torch.Generator().manual_seed(11))
