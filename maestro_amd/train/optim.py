@@ -177,6 +177,11 @@ class EngineAdamW(torch.optim.AdamW):
                 loss = closure()
         eng = self._engine_of()
         if not self._eligible(eng):
+            if self._bound is not None:     # back to torch's implementation: it advances every parameter's OWN step tensor
+                for st in self.state.values():
+                    if "step" in st:
+                        st["step"] = st["step"].clone()
+                self._bound = None          # (the moments stay where they are: views of the flat buffers are ordinary tensors)
             super().step()
             return loss
         if self._bound is not eng:
