@@ -5,41 +5,65 @@
 
 namespace {
 
-// One 1024-thread block per sample (the O(L^2) rank is the start of the forward's critical path: 16 waves, not 4).  rank_i = #{j : n_j < n_i} + #{j < i : n_j == n_i}  (stable ascending order);
-// masked <=> rank < k.  Positions inside the visible / masked lists are exclusive prefix counts (ascending index).
+// One 1024-thread block per sample (the O(L^2) rank is the start of the forward's critical path: 16 waves, not 4).
+// rank_i = #{j : n_j < n_i} + #{j < i : n_j == n_i}  (stable ascending order); masked <=> rank < k.  Positions inside the visible /
+// masked lists are exclusive prefix counts (ascending index).  The rank loop reads the row four keys at a time (LDS broadcast
+// reads of 16 bytes); the prefix counts are wave ballots + popcounts (round 2's serial count over j < i made the launch 91 us
+// at L = 1024 -- two thirds of it in that loop).
 __global__ __launch_bounds__(1024) void mask_select_kernel(const float* __restrict__ noise, const uint8_t* __restrict__ smask,
                                                           int* __restrict__ visible_idx, int* __restrict__ masked_idx,
                                                           int* __restrict__ inv, uint8_t* __restrict__ mask, int L, int k) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // noise[L] then flags[L] (as int)
-    int* flag = reinterpret_cast<int*>(sm + L);
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < L; i += 1024) {
-        float v = noise[(size_t)b * L + i];
-        if (smask && smask[(size_t)b * L + i]) v = 0.f;  // noise *= 1 - struct  (mae.py:240)
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // noise[L4] (padded with +inf to a multiple of 4), then 16 wave totals
+    const int L4 = (L + 3) & ~3;
+    int* wtot = reinterpret_cast<int*>(sm + L4);
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < L4; i += 1024) {
+        float v = INFINITY;
+        if (i < L) {
+            v = noise[(size_t)b * L + i];
+            if (smask && smask[(size_t)b * L + i]) v = 0.f;  // noise *= 1 - struct  (mae.py:240)
+        }
         sm[i] = v;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < L; i += 1024) {
-        const float v = sm[i];
-        int r = 0;
-        for (int j = 0; j < L; ++j) {
-            const float u = sm[j];
-            r += (u < v) || (u == v && j < i);
+    int base = 0;                                  // masked positions before this chunk of 1024 consecutive indices
+    for (int i0 = 0; i0 < L; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        int f = 0;
+        if (i < L) {
+            const float v = sm[i];
+            int r = 0;
+            for (int j = 0; j < L4; j += 4) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(sm + j);
+                r += (int)((u[0] < v) | ((u[0] == v) & (j < i)));
+                r += (int)((u[1] < v) | ((u[1] == v) & (j + 1 < i)));
+                r += (int)((u[2] < v) | ((u[2] == v) & (j + 2 < i)));
+                r += (int)((u[3] < v) | ((u[3] == v) & (j + 3 < i)));
+            }
+            f = r < k;
         }
-        flag[i] = r < k;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < L; i += 1024) {
-        int nm = 0;
-        for (int j = 0; j < i; ++j) nm += flag[j];
-        const int f = flag[i];
-        mask[(size_t)b * L + i] = (uint8_t)f;
-        if (f) {
-            masked_idx[(size_t)b * k + nm] = i;
-            inv[(size_t)b * L + i] = -1;
-        } else {
-            visible_idx[(size_t)b * (L - k) + (i - nm)] = i;
-            inv[(size_t)b * L + i] = i - nm;
+        const unsigned long long bal = __ballot(f);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();                           // (the previous chunk's readers of wtot are done)
+        if (lane == 0) wtot[w] = __popcll(bal);
+        __syncthreads();
+        int nm = base + before, tot = 0;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+            const int c = wtot[x];
+            nm += x < w ? c : 0;
+            tot += c;
+        }
+        base += tot;
+        if (i < L) {
+            mask[(size_t)b * L + i] = (uint8_t)f;
+            if (f) {
+                masked_idx[(size_t)b * k + nm] = i;
+                inv[(size_t)b * L + i] = -1;
+            } else {
+                visible_idx[(size_t)b * (L - k) + (i - nm)] = i;
+                inv[(size_t)b * L + i] = i - nm;
+            }
         }
     }
 }
@@ -167,7 +191,7 @@ extern "C" int mh_mask_select(const float* noise, const uint8_t* struct_mask, in
                               uint8_t* mask, int B, int L, int k, void* stream) {
     MH_CHECK_ARG(noise && visible_idx && masked_idx && inv && mask, "mh_mask_select: null pointer");
     MH_CHECK_ARG(B > 0 && L > 0 && k >= 0 && k <= L && L <= 8192, "mh_mask_select: bad sizes B=%d L=%d k=%d", B, L, k);
-    hipLaunchKernelGGL(mask_select_kernel, dim3(B), dim3(1024), (size_t)L * 8, (hipStream_t)stream, noise, struct_mask,
+    hipLaunchKernelGGL(mask_select_kernel, dim3(B), dim3(1024), (size_t)((L + 3) & ~3) * 4 + 64, (hipStream_t)stream, noise, struct_mask,
                        visible_idx, masked_idx, inv, mask, L, k);
     MH_LAUNCH_CHECK();
     return 0;
