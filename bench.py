@@ -370,7 +370,7 @@ def main() -> None:
             "metric": f"MAE-{args.phase} tiles/sec", "value": round(value, 2), "unit": "tiles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "step_ms": {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3),
-                        "max": round(step_ms[-1], 3), "first": round(step_seq[0], 3),
+                        "max": round(step_ms[-1], 3), "first": round(step_seq[0], 3), "all": [round(x, 2) for x in step_seq],
                         "how": "HIP events on the main stream at every step boundary (this rank); first = the step right after "
                                "the barrier + synchronize (empty GPU queue: the host's issue latency is exposed once)"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
