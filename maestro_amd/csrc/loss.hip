@@ -67,16 +67,20 @@ __global__ __launch_bounds__(256) void masked_loss_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, int is_f32, float* __restrict__ out, int M,
-                                                     int N, int ld, int rows_per_block) {
-    __shared__ f32x4 red[4][64];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// 1024 threads: 16 waves walk the block's rows side by side, 64 lanes x 4 columns each, eight row loads in flight per lane.  The
+// launch is bound by two things that pull in opposite directions -- memory-level parallelism (wants many resident waves) and the
+// same-address atomics of the final add (M / rows_per_block per column: wants few, fat blocks) -- so a block is 16 waves on up to
+// 1024 rows: 32768 x 768 bf16 31.7 -> see scripts/bench_small_reductions.py.
+__global__ __launch_bounds__(1024) void colsum_kernel(const void* __restrict__ x, int is_f32, float* __restrict__ out, int M,
+                                                      int N, int ld, int rows_per_block) {
+    __shared__ f32x4 red[16][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int c = (blockIdx.x * 64 + lane) * 4;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
     f32x4 acc = {0, 0, 0, 0};
     if (c < N) {
-#pragma unroll 8   // independent row loads: keep eight in flight per lane (the loop was latency-bound at ~1 TB/s)
-        for (int r = r0 + w; r < r1; r += 4) {
+#pragma unroll 8   // independent row loads: keep eight in flight per lane
+        for (int r = r0 + w; r < r1; r += nw) {
             if (is_f32) {
                 acc += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + (size_t)r * ld + c);
             } else {
@@ -89,7 +93,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
     red[w][lane] = acc;
     __syncthreads();
     if (w == 0 && c < N) {
-        const f32x4 t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        f32x4 t = red[0][lane];
+        for (int i = 1; i < nw; ++i) t += red[i][lane];
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(out + c + e, t[e]);
     }
@@ -276,12 +281,11 @@ extern "C" int mh_masked_loss_bands(const float* rec, const float* target, const
 
 extern "C" int mh_colsum(const void* x, int x_is_f32, float* out, int M, int N, int ld, void* stream) {
     MH_CHECK_ARG(x && out && N % 4 == 0 && ld % 4 == 0, "mh_colsum: bad arguments");
-    // 128-256 rows per block: fewer rows mean more workgroups but also more same-address atomics per column (32-row blocks
-    // took 57 us for 32768 x 768 bf16, 256-row blocks 32 us; 12800 x 200: 41 -> 15 us), more rows starve the CUs
+    // up to 1024 rows per 16-wave block; fewer when that would leave most CUs without a block
     const int col_blocks = ceil_div(N, 256);
-    int rows_per_block = 256;
-    if ((long)col_blocks * ceil_div(M, rows_per_block) < 256) rows_per_block = 128;
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 256), ceil_div(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream, x,
+    int rows_per_block = 1024;
+    while (rows_per_block > 128 && (long)col_blocks * ceil_div(M, rows_per_block) < 128) rows_per_block >>= 1;
+    hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, ceil_div(M, rows_per_block)), dim3(1024), 0, (hipStream_t)stream, x,
                        x_is_f32, out, M, N, ld, rows_per_block);
     MH_LAUNCH_CHECK();
     return 0;

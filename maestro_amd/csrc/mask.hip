@@ -132,31 +132,44 @@ __global__ __launch_bounds__(256) void unmask_kernel(const float* __restrict__ y
 }
 
 // dmask_token[:] (ONE row = the gradient of modality `slot`'s mask token) += sum over its masked tokens; each block reduces a strip of token rows in registers first.
-constexpr int UM_ROWS = 128;  // rows per block: keeps the same-address atomics per column at B*L/128 instead of B*L/16
-__global__ __launch_bounds__(256) void unmask_bwd_token_kernel(const float* __restrict__ dxdec, const uint8_t* __restrict__ mask,
-                                                               const int* __restrict__ tok_slot, float* __restrict__ dmask_token,
-                                                               int B, int L, int Dd, int slot, int t_lo, int t_hi, int slot_stride) {
-    // grid: ceil(B*(t_hi-t_lo) / UM_ROWS); the 256 threads are (row lane, float4 column): Dd/4 <= 256 columns, 256/(Dd/4)
-    // rows side by side; four independent row loads in flight per thread (the row predicate is applied to the loaded value's
-    // use, not to a branch around a dependent chain: 70 -> ~20 us at 32768 x 512)
-    __shared__ __attribute__((aligned(16))) float red[256 * 4];
+// Round 3: 1024 threads and 512 rows per block instead of 256 / 128 -- the launch was bound by its memory-level parallelism (two
+// row lanes x four loads per block) and by B*L/128 same-address atomics per column (36 MB in 46 us = 0.8 TB/s at 32768 x 512).
+constexpr int UM_ROWS = 512, UM_NT = 1024;
+__global__ __launch_bounds__(UM_NT) void unmask_bwd_token_kernel(const float* __restrict__ dxdec, const uint8_t* __restrict__ mask,
+                                                                 const int* __restrict__ tok_slot, float* __restrict__ dmask_token,
+                                                                 int B, int L, int Dd, int slot, int t_lo, int t_hi, int slot_stride) {
+    // grid: ceil(B*(t_hi-t_lo) / UM_ROWS); the threads are (row lane, float4 column): Dd/4 <= 256 columns, UM_NT/(Dd/4) rows side
+    // by side; four independent row loads in flight per thread (the row predicate is applied to the loaded value's use, not to
+    // a branch around a dependent chain)
+    __shared__ __attribute__((aligned(16))) float red[UM_NT * 4];
+    __shared__ int row_off[UM_ROWS];               // element offset of a contributing row's start, -1 otherwise
     const int span = t_hi - t_lo, total = B * span;
-    const int cols = Dd >> 2, lanes = 256 / cols;
+    const int cols = Dd >> 2, lanes = UM_NT / cols;
     const int col = threadIdx.x % cols, sub = threadIdx.x / cols;
     const int r0 = blockIdx.x * UM_ROWS;
+    // the row predicates first (mask byte + slot id are two loads the row's data load would otherwise wait for: with them in the
+    // loop the launch was a chain of dependent memory latencies, 47 us for 36 MB whatever the block shape)
+    for (int rr = threadIdx.x; rr < UM_ROWS; rr += UM_NT) {
+        const int r = r0 + rr;
+        int off = -1;
+        if (r < total) {
+            const int b = r / span, t = t_lo + (r - b * span);
+            if (mask[(size_t)b * L + t] && tok_slot[(size_t)b * slot_stride + t] == slot) off = b * L + t;
+        }
+        row_off[rr] = off;
+    }
+    __syncthreads();
     f32x4 acc = {0, 0, 0, 0};
     if (sub < lanes) {
+#pragma unroll 2
         for (int rr = sub; rr < UM_ROWS; rr += 4 * lanes) {
             f32x4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int r = r0 + rr + u * lanes;
                 v[u] = (f32x4){0, 0, 0, 0};
-                if (rr + u * lanes < UM_ROWS && r < total) {
-                    const int b = r / span, t = t_lo + (r - b * span);
-                    if (mask[(size_t)b * L + t] && tok_slot[(size_t)b * slot_stride + t] == slot)
-                        v[u] = *reinterpret_cast<const f32x4*>(dxdec + ((size_t)b * L + t) * Dd + 4 * col);
-                }
+                const int ri = rr + u * lanes;
+                const int off = ri < UM_ROWS ? row_off[ri] : -1;
+                if (off >= 0) v[u] = *reinterpret_cast<const f32x4*>(dxdec + (size_t)off * Dd + 4 * col);
             }
             acc += (v[0] + v[1]) + (v[2] + v[3]);
         }
@@ -249,7 +262,7 @@ extern "C" int mh_unmask_token_grad(const float* dxdec, const uint8_t* mask, con
                                     int L, int Dd, int slot, int t_lo, int t_hi, void* stream) {
     MH_CHECK_ARG(dxdec && mask && tok_slot && dmask_token && Dd % 4 == 0 && Dd <= 1024, "mh_unmask_token_grad: bad arguments");
     MH_CHECK_ARG(0 <= t_lo && t_lo < t_hi && t_hi <= L, "mh_unmask_token_grad: bad token range");
-    hipLaunchKernelGGL(unmask_bwd_token_kernel, dim3(ceil_div((long)B * (t_hi - t_lo), UM_ROWS)), dim3(256), 0,
+    hipLaunchKernelGGL(unmask_bwd_token_kernel, dim3(ceil_div((long)B * (t_hi - t_lo), UM_ROWS)), dim3(UM_NT), 0,
                        (hipStream_t)stream, dxdec, mask, tok_slot, dmask_token, B, L, Dd, slot, t_lo, t_hi, 0);
     MH_LAUNCH_CHECK();
     return 0;
@@ -259,7 +272,7 @@ extern "C" int mh_unmask_token_grad_per_sample(const float* dxdec, const uint8_t
                                                int B, int L, int Dd, int slot, void* stream) {
     MH_CHECK_ARG(dxdec && mask && tok_slot_bl && dmask_token && Dd % 4 == 0 && Dd <= 1024 && B > 0 && L > 0,
                  "mh_unmask_token_grad_per_sample: bad arguments");
-    hipLaunchKernelGGL(unmask_bwd_token_kernel, dim3(ceil_div((long)B * L, UM_ROWS)), dim3(256), 0, (hipStream_t)stream, dxdec, mask,
+    hipLaunchKernelGGL(unmask_bwd_token_kernel, dim3(ceil_div((long)B * L, UM_ROWS)), dim3(UM_NT), 0, (hipStream_t)stream, dxdec, mask,
                        tok_slot_bl, dmask_token, B, L, Dd, slot, 0, L, L);
     MH_LAUNCH_CHECK();
     return 0;
