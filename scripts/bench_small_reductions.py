@@ -26,3 +26,9 @@ for M, N, f32 in ((32768, 1024, False), (32768, 768, False), (32768, 512, False)
     x = torch.randn(M, N, device=dev).to(torch.float32 if f32 else torch.bfloat16); out = torch.zeros(N, device=dev)
     us = t(lambda: hip.colsum(x, out, M, N, N))
     print(f"colsum ({M},{N}) {'f32' if f32 else 'bf16'}: {us:6.1f} us  {x.numel() * x.element_size() / us / 1e3:5.0f} GB/s", flush=True)
+for B, D, L, E in ((32, 1, 1024, 768), (32, 16, 25, 768)):
+    y = torch.randn(B * D * L, E, device=dev); dxg = torch.randn(B, D * L, E, device=dev); gamma = torch.randn(E, device=dev)
+    stats = torch.rand(B * D, 2, device=dev) + 0.5; dyc = torch.empty(B * D * L, E, device=dev, dtype=torch.bfloat16)
+    dg, db, sums = torch.zeros(E, device=dev), torch.zeros(E, device=dev), torch.zeros(B * D, 2, device=dev)
+    us = t(lambda: hip.embed_finish_bwd(dxg, y, stats, gamma, dyc, dg, db, sums, B, D, L, E, 0, D * L))
+    print(f"embed_finish_bwd (stats + apply) B={B} D={D} L={L} E={E}: {us:6.1f} us  {y.numel() * (16 + 2) / us / 1e3:5.0f} GB/s", flush=True)

@@ -133,7 +133,7 @@ def test_patchify(dev, BD, C, S, P, norm_bands, elev, normalise):
     assert (target.cpu() - tgt.reshape(-1, K)).abs().max() < 2e-4
 
 
-@pytest.mark.parametrize("B,D,L,E,tok_off,Lg", [(2, 1, 64, 192, 0, 64), (2, 3, 25, 768, 10, 100), (1, 4, 9, 1024, 36, 72)])
+@pytest.mark.parametrize("B,D,L,E,tok_off,Lg", [(2, 1, 64, 192, 0, 64), (2, 3, 25, 768, 10, 100), (1, 4, 9, 1024, 36, 72), (2, 1, 600, 384, 8, 640)])
 def test_groupnorm_embed_finish_fwd_bwd(dev, B, D, L, E, tok_off, Lg):
     from maestro_amd import hip
     y = (_rand(B * D * L, E, seed=1) * 1.7 + 0.3).to(dev)
