@@ -413,3 +413,70 @@ def test_dropped_engines_retire_their_graphs(monkeypatch):
     assert destroyed == [1] and synced == [1] and not engine._RETIRED_GRAPHS
     engine.drain_retired_graphs()                            # nothing retired: no synchronisation
     assert synced == [1]
+
+
+def test_engine_adamw_without_an_engine_is_torch_adamw():
+    """``EngineAdamW`` (what ``configure_optimizers`` returns) before any engine owns the parameters: torch's own step, torch's
+    state layout; a closure is evaluated with gradients enabled (Lightning's automatic optimisation runs the step inside it)."""
+    import io
+
+    from maestro_amd.train.optim import EngineAdamW
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa = EngineAdamW(a, lambda: None, lr=0.05, betas=(0.9, 0.99), weight_decay=0.01)
+    ob = torch.optim.AdamW(b, lr=0.05, betas=(0.9, 0.99), weight_decay=0.01)
+    assert isinstance(oa, torch.optim.AdamW)
+    for step in range(3):
+        g = [torch.randn_like(p, generator=torch.Generator().manual_seed(10 * step + i)) for i, p in enumerate(a)]
+        for p, q, gi in zip(a, b, g):
+            p.grad, q.grad = gi.clone(), gi.clone()
+        seen = []
+
+        def closure():
+            seen.append(torch.is_grad_enabled())
+            return torch.tensor(1.5)
+
+        assert float(oa.step(closure)) == 1.5 and seen == [True]
+        ob.step()
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+    sd = oa.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 3.0
+    assert sd["state"][0]["step"] is not sd["state"][1]["step"]           # never a shared counter in a checkpoint
+    buf = io.BytesIO()
+    torch.save(sd, buf)
+    buf.seek(0)
+    ob2 = torch.optim.AdamW(b, lr=0.05, betas=(0.9, 0.99), weight_decay=0.01)
+    ob2.load_state_dict(torch.load(buf, weights_only=False))
+    oa.load_state_dict(ob.state_dict())
+    assert oa._bound is None
+    for p, q in zip(a, b):
+        p.grad, q.grad = torch.ones_like(p), torch.ones_like(q)
+    oa.step()
+    ob2.step()
+    for p, q in zip(a, b):
+        assert torch.allclose(p, q, rtol=0, atol=1e-7)
+
+
+def test_engine_adamw_falls_back_when_it_does_not_cover_the_engine():
+    """Several parameter groups, or gradients that are not the engine's flat-buffer slices: torch's implementation runs."""
+    from types import SimpleNamespace
+
+    from maestro_amd.train.optim import EngineAdamW
+    w = [torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(2))]
+    flat_grad = torch.zeros(8)
+    store = SimpleNamespace(params=w, offset={id(w[0]): 0, id(w[1]): 4}, total=8, fresh=False,
+                            g=lambda p: flat_grad[0:4] if p is w[0] else flat_grad[4:6])
+    eng = SimpleNamespace(store=store)
+    two_groups = EngineAdamW([{"params": [w[0]]}, {"params": [w[1]], "lr": 0.5}], lambda: eng, lr=0.1)
+    assert not two_groups._eligible(eng)
+    one = EngineAdamW(w, lambda: eng, lr=0.1)
+    w[0].grad, w[1].grad = torch.ones(4), torch.ones(2)                   # ordinary tensors, not the flat buffer's slices
+    assert not one._eligible(eng)
+    w[0].grad, w[1].grad = flat_grad[0:4], flat_grad[4:6]
+    assert one._eligible(eng)
+    store.fresh = True                                                    # no backward has written the buffer yet
+    assert not one._eligible(eng)
+    one.step()                                                            # (torch's path: must simply work)
+    assert one._fused is None
