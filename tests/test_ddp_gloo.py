@@ -208,6 +208,23 @@ def _slot_worker(rank, world, port, out):
               and eng4.in_flight[1] == [(600, n + 64), (250, 600)]
               and abs(float(cb4.loss_mean) - 15.0) < 1e-6 and not cb4._exchanged_in_backward)
     cb_ok = cb_ok and ovl_ok
+    # probe phase: only the heads [lo, total) have gradients -- the buckets cover [lo, total + slot), the frozen part is not sent
+    eng5 = _FakeEngine(n, rank)
+    eng5.store.params, eng5.store.fresh, eng5.trainable_span = [], True, (400, n)
+    cb5 = EngineDDPCallback(bucket_mb=1, overlap=True)
+    cb5.bucket_bytes = 4 * 300
+    mod5 = SimpleNamespace(model=SimpleNamespace(_engine=None, _sup_engine=eng5))
+    loss5 = _EngineLoss.apply(torch.zeros((), requires_grad=True), eng5, eng5.loss_acc)
+    cb5.on_before_backward(None, mod5, loss5)
+    loss5.backward()
+    cb5.on_after_backward(None, mod5)
+    ramp = torch.arange(n, dtype=torch.float32)
+    # below lo: this rank's own values, never exchanged (the bridge's 1 / world scaling pass covers the whole buffer; harmless:
+    # frozen parameters get grad = None)
+    want5 = torch.where(ramp >= 400, ramp * 1.5, ramp * (rank + 1) * 0.5)
+    probe_ok = torch.equal(eng5.store.grad, want5) and all(lo_ >= 0 and hi_ <= n - 400 + 64 for lo_, hi_ in cb5._sync.launched) \
+        and cb5._sync.grad.numel() == n - 400 + 64
+    cb_ok = cb_ok and probe_ok
     met = MeanMetric()
     met.update(torch.tensor(float(rank + 1)))
     met.update(3.0 * (rank + 1))
