@@ -15,6 +15,8 @@ ds, model = bench.build_model("c3")
 loop = PretrainLoop(model, 32, dev, total_steps=100)
 batch = synthetic_batch(ds.dataset, 32, dev)
 eng = loop.engine
+if os.environ.get("EAGER"):
+    eng.use_graphs = False
 rows = []
 for it in range(STEPS):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
