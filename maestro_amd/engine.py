@@ -561,6 +561,13 @@ class EngineBase:
         self.instep_tune = (os.environ.get("MAESTRO_INSTEP_TUNE", "0") == "1" and not self.tune_gemm
                             and not any(os.environ.get(k) for k in ("MH_GEMM_TILE", "MH_GEMM_DMA", "MH_GEMM_PP", "MH_DMA_STAGGER")))
         self.tile_report = None     # {signature: (picked tile, {candidate: ms})} of this engine's tuning passes
+        # MAESTRO_WARM_PASSES (default 6): the first step recomputes its own forward + backward that many extra times (same inputs,
+        # same draws, no optimizer update, no gradient exchange) before it runs for real.  On this platform some of the first ~8
+        # steps of a process run their forward ~1 ms (15 %) slower whatever the launch mode (graphs or eager, one stream or
+        # several: scripts/step_phases.py) -- a start-up effect of ~100-150 ms of load that would otherwise sit in the first
+        # optimizer steps of every run.  Results are unchanged (the passes overwrite the same buffers with the same values);
+        # not with fp8 (amax history) or an optimizer captured into the forward.  0 disables.
+        self.warm_passes = int(os.environ.get("MAESTRO_WARM_PASSES", "6"))
         # the GELU derivative saved by the fc1 epilogue for the backward: one byte per element (MH_GEMM_AUX_U8, step 0.005 on
         # [-0.129, 1.129]) instead of bf16 -- 1.7 GB less HBM traffic per C3 step; MAESTRO_AUX_U8=0 keeps bf16
         self.aux_flag = hip.AUX_U8 if os.environ.get("MAESTRO_AUX_U8", "1") == "1" else 0
@@ -643,6 +650,23 @@ class EngineBase:
         finally:
             hip.set_instep_tuner(None)
             self.use_graphs, self.multi_stream, self.grad_hook = saved
+
+    def _warm_up(self, one_pass) -> None:
+        """``one_pass()``: forward + zero_grad + backward of the current step (same inputs, same draws); see ``warm_passes``."""
+        n, self.warm_passes = self.warm_passes, 0
+        if (n <= 0 or getattr(self, "fp8", None) is not None or getattr(self, "_opt", None) is not None
+                or hip.kernel_timer_active() or torch.cuda.is_current_stream_capturing()):
+            return
+        # eager launches: nothing is captured here (an engine that only ever runs one step -- most tests -- owns no hipGraph)
+        hook, graphs = self.grad_hook, self.use_graphs
+        self.use_graphs = False
+        if hook is not None:
+            self.grad_hook = lambda lo, hi: None      # same launch plan, nothing handed to the exchange
+        try:
+            for _ in range(n):
+                one_pass()
+        finally:
+            self.grad_hook, self.use_graphs = hook, graphs
 
     @contextlib.contextmanager
     def _tuning_pass(self, what: str):
@@ -942,6 +966,12 @@ class MAEEngine(EngineBase):
                 self.zero_grad()
                 self.backward()
             self._instep_tune(one_pass)
+        if self.warm_passes > 0:
+            def warm_pass():
+                self.forward(batch, noise=noise, struct=struct)
+                self.zero_grad()
+                self.backward()
+            self._warm_up(warm_pass)
         # host -> pinned ring slot -> device (outside any graph).  A slot is reused every RING steps; only then do we wait
         # for the async copies that last read it (the host may run several steps ahead of the GPU, but a per-step
         # hipEventSynchronize was measured to wake up ~10 ms late and starve the queue).

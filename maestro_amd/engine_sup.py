@@ -143,6 +143,12 @@ class SupervisedEngine(EngineBase):
                 self.zero_grad()
                 self.backward()
             self._instep_tune(one_pass)
+        if self.warm_passes > 0:       # start-up passes of the first step (engine.py: warm_passes)
+            def warm_pass():
+                self.forward(batch)
+                self.zero_grad()
+                self.backward()
+            self._warm_up(warm_pass)
         batch = dict(batch)
         sources = [parts[0] for parts in self.model.src_specs.values()]      # one spec per batch entry (band-group 0)
         for s in sources:
