@@ -10,6 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $out/${tag}_bench_c3_n1.json 2> $out/${tag}_bench.err || exit 1
 tail -c 600 $out/${tag}_bench_c3_n1.json; echo
 common="--cpu-seconds 0 --no-kernel-timing"
+# the traces are normalised per step (13 = 3 warm-up + 10 timed; counters: 5): no start-up passes of the first step in them
+export MAESTRO_WARM_PASSES=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks -o ${tag} -- python $R/bench.py --steps 10 --warmup 3 $common > $out/ks.log 2>&1 || exit 2
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks1 -o ${tag}_single_stream -- python $R/bench.py --steps 10 --warmup 3 --single-stream $common > $out/ks1.log 2>&1 || exit 3
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf -o ${tag}_fetch -- python $R/bench.py --steps 2 --warmup 3 $common > $out/pf.log 2>&1 || exit 4
