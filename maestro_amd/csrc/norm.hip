@@ -80,6 +80,58 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
+// Straight-line forward for the step's own case (dim == 256 * NV: every lane holds NV float4; bf16 output, no e4m3 copy).
+// Same operations in the same order as ln_fwd_kernel (results equal up to the compiler's fma contraction: a few fp32 ulp,
+// tests/test_kernels_gpu.py), but no lane predicates and no output-type branches, so that the code is ONE scheduling region.  In the generic kernel's ISA (gfx950, -O3) every predicated chunk
+// ends in `s_waitcnt vmcnt(0)`: the row's NV loads went out as NV dependent round trips, gamma / beta were fetched after
+// the two reductions, chunk by chunk, and each chunk's wait also covered the previous chunk's STORES -- 7-8 memory round
+// trips per row, one after the other.  Here the row, gamma and beta are requested back to back before anything is
+// waited for, and the stores leave together at the end.
+#ifndef MH_LN_FAST
+#define MH_LN_FAST 1      // -DMH_LN_FAST=0 (MH_BUILD_FLAGS) builds the library without the straight-line forms (A/B aid)
+#endif
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const float* __restrict__ x, RowMap xm, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, bf16_t* __restrict__ y, RowMap ym,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, int B, int n,
+                                                          float eps) {
+    constexpr int dim = 256 * NV;
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B * n) return;
+    const int b = row / n, j = row - b * n;
+    const float* xr = x + map_row(xm, b, j) * dim;
+    f32x4 v[NV], g[NV], bt[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * (lane + 64 * i));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        g[i] = *reinterpret_cast<const f32x4*>(gamma + 4 * (lane + 64 * i));
+        bt[i] = *reinterpret_cast<const f32x4*>(beta + 4 * (lane + 64 * i));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mu = wave_sum(s) / dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; }
+    }
+    const float rs = rsqrtf(wave_sum(q) / dim + eps);
+    bf16_t* yr = y + map_row(ym, b, j) * dim;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[i][e] + bt[i][e];
+        const u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+        *reinterpret_cast<u32x2*>(yr + 4 * (lane + 64 * i)) = pk;
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
 // Backward. Each wave walks ROWS_PER_WAVE rows keeping per-column partials of dgamma, dbeta and colsum(dx) in
 // registers; the block reduces them through LDS and writes ONE partial row [3*dim] to the workspace (plain stores);
 // ln_bwd_reduce_kernel then sums the partial rows (few atomics per column, no same-address storm).
@@ -201,6 +253,108 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         prow[c] = red[c] + red[3 * dim + c] + red[6 * dim + c] + red[9 * dim + c];
 }
 
+// Straight-line backward for the transformer blocks' own case: dim == 256 * NV, bf16 dy, a residual gradient to add, a bf16
+// copy of dx to write, rows % ROWS_PER_WAVE == 0 (a wave's rows exist together).  Same operations, same order, same
+// partial-row layout as ln_bwd_kernel (results equal up to fma contraction / packing: a few fp32 ulp).  Why it exists: in the generic kernel the run-time cases
+// (dy type, dres / dx_bf16 present, lane < nv) are branches INSIDE the software pipeline; its ISA waits `vmcnt(0)` after
+// each chunk's dy load (the bf16 words are moved into the f32-sized registers of the other case) and again at the loop
+// head (store counts are not static across the branches), so the "prefetch" of the next row was NV + 1 dependent round
+// trips and also waited for the previous row's stores: ~5 us per row and wave, whatever the bandwidth.  Here the wave's
+// rows are unrolled, the operands of DEPTH rows are in flight before the first one is reduced, the waits carry exact
+// counts, and the sched_barriers pin the issue order (loads of row r + DEPTH, then the arithmetic and stores of row r).
+template <int NV, int DEPTH>
+__global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const bf16_t* __restrict__ dy, RowMap dym, const float* __restrict__ x,
+                                                          RowMap xm, const float* __restrict__ gamma,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ dres, float* __restrict__ dx,
+                                                          bf16_t* __restrict__ dx_bf16, float* __restrict__ partial, int B, int n) {
+    constexpr int dim = 256 * NV;
+    static_assert(DEPTH >= 1 && DEPTH <= ROWS_PER_WAVE, "prefetch distance in rows");
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][3][dim]
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    f32x4 gsum[NV], bsum[NV], csum[NV], gm[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        gsum[i] = (f32x4){0, 0, 0, 0}; bsum[i] = (f32x4){0, 0, 0, 0}; csum[i] = (f32x4){0, 0, 0, 0};
+        gm[i] = *reinterpret_cast<const f32x4*>(gamma + 4 * (lane + 64 * i));
+    }
+    const int row0 = (blockIdx.x * 4 + w) * ROWS_PER_WAVE;
+    if (row0 < B * n) {
+        f32x4 xq[ROWS_PER_WAVE][NV], rq[ROWS_PER_WAVE][NV];
+        u32x2 dq[ROWS_PER_WAVE][NV];
+        float muq[ROWS_PER_WAVE], rsq[ROWS_PER_WAVE];
+        size_t xrowq[ROWS_PER_WAVE];
+        auto fetch = [&](int p) {
+            const int row = row0 + p, b = row / n, j = row - b * n;
+            xrowq[p] = map_row(xm, b, j) * dim;
+            const size_t dyrow = map_row(dym, b, j) * dim;
+            muq[p] = mean[row]; rsq[p] = rstd[row];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c4 = 4 * (lane + 64 * i);
+                xq[p][i] = *reinterpret_cast<const f32x4*>(x + xrowq[p] + c4);
+                dq[p][i] = *reinterpret_cast<const u32x2*>(dy + dyrow + c4);
+                rq[p][i] = *reinterpret_cast<const f32x4*>(dres + xrowq[p] + c4);
+            }
+        };
+#pragma unroll
+        for (int p = 0; p < DEPTH; ++p) fetch(p);
+#pragma unroll
+        for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+            if (rr + DEPTH < ROWS_PER_WAVE) fetch(rr + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+            const float mu = muq[rr], rs = rsq[rr];
+            f32x4 xh[NV], dz[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const u32x2 pk = dq[rr][i];
+                const f32x4 d = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
+                                 __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xq[rr][i][e] - mu) * rs;
+                    dz[i][e] = d[e] * gm[i][e];
+                    s1 += dz[i][e];
+                    s2 += dz[i][e] * xh[i][e];
+                    gsum[i][e] += d[e] * xh[i][e];
+                    bsum[i][e] += d[e];
+                }
+            }
+            const float c1 = wave_sum(s1) / dim, c2 = wave_sum(s2) / dim;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c4 = 4 * (lane + 64 * i);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (dz[i][e] - c1 - xh[i][e] * c2);
+                o += rq[rr][i];
+                csum[i] += o;
+                *reinterpret_cast<f32x4*>(dx + xrowq[rr] + c4) = o;
+                const u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+                *reinterpret_cast<u32x2*>(dx_bf16 + xrowq[rr] + c4) = pk;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (!partial) return;
+    float* rg = red + (size_t)w * 3 * dim;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c4 = 4 * (lane + 64 * i);
+        *reinterpret_cast<f32x4*>(rg + c4) = gsum[i];
+        *reinterpret_cast<f32x4*>(rg + dim + c4) = bsum[i];
+        *reinterpret_cast<f32x4*>(rg + 2 * dim + c4) = csum[i];
+    }
+    __syncthreads();
+    float* prow = partial + (size_t)blockIdx.x * 3 * dim;
+    for (int c = threadIdx.x; c < 3 * dim; c += 256)
+        prow[c] = red[c] + red[3 * dim + c] + red[6 * dim + c] + red[9 * dim + c];
+}
+
+#ifndef LN_BWD_DEPTH
+#define LN_BWD_DEPTH 4    // rows of operands in flight per wave before the first is reduced (dim <= 768)
+#endif
 constexpr int RED_ROWS = 8;   // 8 partial rows per thread: short dependent-free load chains, 4x more (cheap) atomics
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int dim,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -227,8 +381,15 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(const MhColsumJob* 
     const int r0 = (int)(e & 0xFFFFFFFFu) * MH_COLSUM_ROWS;
     if (c >= j.cols || r0 >= j.rows) return;
     const int r1 = min(j.rows, r0 + MH_COLSUM_ROWS);
+    // the chunk's loads go out together (the rolled loop was load -> s_waitcnt vmcnt(0) -> add: MH_COLSUM_ROWS dependent
+    // round trips per thread); the adds keep their order
+    const float* src = j.src + (size_t)r0 * j.ld + c;
+    float v[MH_COLSUM_ROWS];
+#pragma unroll
+    for (int i = 0; i < MH_COLSUM_ROWS; ++i) v[i] = r0 + i < r1 ? src[(size_t)i * j.ld] : 0.f;
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += j.src[(size_t)r * j.ld + c];
+#pragma unroll
+    for (int i = 0; i < MH_COLSUM_ROWS; ++i) s += v[i];
     atomicAdd(j.dst + c, s);
 }
 
@@ -265,8 +426,17 @@ static int layernorm_fwd_impl(const float* x, int x_L, int x_off, const float* g
     hipStream_t s = (hipStream_t)stream;
 #define LN_FWD(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, grid, block, 0, s, x, RowMap{x_L, x_off}, gamma, beta, y, \
                                       RowMap{y_L, y_off}, y_is_f32, mean, rstd, B, n, dim, eps, (uint8_t*)y8, y8_scale, y8_amax)
-    switch (ln_nv(dim)) { case 1: LN_FWD(1); break; case 2: LN_FWD(2); break; case 3: LN_FWD(3); break;
-                          case 4: LN_FWD(4); break; default: LN_FWD(8); }
+#define LN_FWD_FAST(NV) hipLaunchKernelGGL(ln_fwd_fast_kernel<NV>, grid, block, 0, s, x, RowMap{x_L, x_off}, gamma, beta, \
+                                           (bf16_t*)y, RowMap{y_L, y_off}, mean, rstd, B, n, eps)
+    const int nvs = ln_nv(dim);
+    if (MH_LN_FAST && nvs <= 4 && dim == 256 * nvs && !y_is_f32 && !y8) {     // the step's own case: straight-line kernel
+        switch (nvs) { case 1: LN_FWD_FAST(1); break; case 2: LN_FWD_FAST(2); break; case 3: LN_FWD_FAST(3); break;
+                       default: LN_FWD_FAST(4); }
+    } else {
+        switch (nvs) { case 1: LN_FWD(1); break; case 2: LN_FWD(2); break; case 3: LN_FWD(3); break;
+                       case 4: LN_FWD(4); break; default: LN_FWD(8); }
+    }
+#undef LN_FWD_FAST
 #undef LN_FWD
     MH_LAUNCH_CHECK();
     return 0;
@@ -287,8 +457,19 @@ static int layernorm_bwd_impl(const void* dy, int dy_L, int dy_off, int dy_is_f3
     float* part = (dgamma || partial_only) ? workspace : nullptr;
 #define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, grid, block, lds, s, dy, RowMap{dy_L, dy_off}, dy_is_f32, x, \
                                       RowMap{x_L, x_off}, gamma, mean, rstd, dres, dx, (bf16_t*)dx_bf16, part, B, n, dim)
-    switch (ln_nv(dim)) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break;
-                          case 4: LN_BWD(4); break; default: LN_BWD(8); }
+#define LN_BWD_FAST(NV, DEPTH) hipLaunchKernelGGL((ln_bwd_fast_kernel<NV, DEPTH>), grid, block, lds, s, (const bf16_t*)dy, \
+                                                  RowMap{dy_L, dy_off}, x, RowMap{x_L, x_off}, gamma, mean, rstd, dres, dx, \
+                                                  (bf16_t*)dx_bf16, part, B, n)
+    const int nvs = ln_nv(dim);
+    if (MH_LN_FAST && nvs <= 4 && dim == 256 * nvs && !dy_is_f32 && dres && dx_bf16 && rows % ROWS_PER_WAVE == 0) {
+        // the transformer blocks' own case: straight-line kernel, all of a wave's rows in flight (two at dim 1024: registers)
+        switch (nvs) { case 1: LN_BWD_FAST(1, LN_BWD_DEPTH); break; case 2: LN_BWD_FAST(2, LN_BWD_DEPTH); break;
+                       case 3: LN_BWD_FAST(3, LN_BWD_DEPTH); break; default: LN_BWD_FAST(4, 2); }
+    } else {
+        switch (nvs) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break;
+                       case 4: LN_BWD(4); break; default: LN_BWD(8); }
+    }
+#undef LN_BWD_FAST
 #undef LN_BWD
     if (dgamma && !partial_only)
         hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(3 * dim, 256), ceil_div(nblk, RED_ROWS)), dim3(256), 0, s,

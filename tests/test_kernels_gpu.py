@@ -23,7 +23,10 @@ def _rand(*shape, seed=0, scale=1.0):
 
 # ----------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("dim,B,n,xL,xoff,yL,yoff", [(768, 3, 50, 50, 0, 50, 0), (512, 2, 37, 64, 20, 40, 3),
-                                                      (192, 4, 16, 16, 0, 30, 14), (1024, 1, 9, 9, 0, 9, 0)])
+                                                      (192, 4, 16, 16, 0, 30, 14), (1024, 1, 9, 9, 0, 9, 0),
+                                                      # rows % 4 == 0 and dim == 256 k: the straight-line kernels (norm.hip)
+                                                      (768, 2, 52, 60, 3, 64, 5), (512, 4, 16, 16, 0, 16, 0),
+                                                      (256, 3, 8, 11, 2, 8, 0), (1024, 2, 6, 6, 0, 9, 3)])
 @pytest.mark.parametrize("out_f32", [False, True])
 def test_layernorm_fwd_bwd(dev, dim, B, n, xL, xoff, yL, yoff, out_f32):
     from maestro_amd import hip
@@ -53,6 +56,52 @@ def test_layernorm_fwd_bwd(dev, dim, B, n, xL, xoff, yL, yoff, out_f32):
     assert (dxb[:, xoff:xoff + n].float() - ref_dx).abs().max() < 3e-2
     assert (dg - g_ref.grad).abs().max() < 2e-3 and (db - b_ref.grad).abs().max() < 2e-3
     assert (dc - (1 + ref_dx.sum((0, 1)))).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("dim,B,n,xL,xoff,yL,yoff", [(768, 2, 32, 40, 5, 36, 2), (512, 3, 16, 16, 0, 20, 4), (256, 1, 64, 64, 0, 64, 0),
+                                                      (1024, 2, 24, 30, 6, 24, 0), (768, 32, 256, 256, 0, 256, 0),
+                                                      (512, 32, 1024, 1024, 0, 1024, 0)])
+def test_layernorm_straight_line_forms_equal_generic(dev, dim, B, n, xL, xoff, yL, yoff):
+    """The straight-line kernels (dim == 256 k, bf16 in / out, rows % 4 == 0: what the transformer blocks launch) against the
+    generic kernels on the same values, up to the step's own launch sizes (8192 x 768, 32768 x 512).  Same operations in the
+    same order; only the compiler's fma contraction / packing differs between the two forms, so the fp32 results agree to
+    a few ulp (1e-5 here; a wrong row, lane or partial would be off by O(1)) and the bf16 ones to one bf16 ulp.  The generic
+    forward is reached through an fp32 output, the generic backward through an fp32 dy that holds the bf16 values."""
+    from maestro_amd import hip
+    x = _rand(B, xL, dim, seed=11).to(dev) * 1.7 - 0.3
+    gamma, beta = (1 + 0.2 * _rand(dim, seed=12)).to(dev), (0.1 * _rand(dim, seed=13)).to(dev)
+    rows = B * n
+    ya = torch.full((B, yL, dim), 7.0, device=dev, dtype=torch.bfloat16)
+    yb = torch.full((B, yL, dim), 7.0, device=dev)
+    stats = [torch.empty(rows, device=dev) for _ in range(4)]
+    hip.layernorm_fwd(x, xL, xoff, gamma, beta, ya, yL, yoff, stats[0], stats[1], B, n, dim)
+    hip.layernorm_fwd(x, xL, xoff, gamma, beta, yb, yL, yoff, stats[2], stats[3], B, n, dim)
+
+    def close16(a, b):          # bf16 roundings of fp32 numbers that agree to ~1e-5 of the tensor's scale: one bf16 ulp apart at most
+        a, b = a.float(), b.float()
+        return bool(((a - b).abs() <= 2.0 ** -7 * b.abs() + 2e-5 * max(1.0, b.abs().max().item())).all())
+    assert close16(ya, yb.bfloat16()) and (ya != yb.bfloat16()).float().mean() < 2e-2
+    assert torch.allclose(stats[0], stats[2], rtol=1e-6, atol=1e-7) and torch.allclose(stats[1], stats[3], rtol=1e-6, atol=1e-7)
+    dy = _rand(B, yL, dim, seed=14).to(dev).bfloat16()
+    dres = _rand(B, xL, dim, seed=15).to(dev)
+    n_ws = hip.layernorm_bwd_workspace(rows, dim)
+    out = []
+    for dy_in in (dy, dy.float()):
+        dx = torch.full((B, xL, dim), 3.0, device=dev)
+        dxb = torch.full((B, xL, dim), 3.0, device=dev, dtype=torch.bfloat16)
+        ws = torch.full((n_ws,), float("nan"), device=dev)
+        hip.layernorm_bwd_partial(dy_in, yL, yoff, x, xL, xoff, gamma, stats[0], stats[1], dres, dx, dxb, ws, B, n, dim)
+        out.append((dx, dxb, ws))
+    torch.cuda.synchronize()
+    (dx_a, dxb_a, ws_a), (dx_b, dxb_b, ws_b) = out
+    err = (dx_a - dx_b).abs().max().item()
+    assert err < 1e-5 * max(1.0, dx_b.abs().max().item()), err
+    assert close16(dxb_a, dxb_b) and (dxb_a != dxb_b).float().mean() < 2e-2
+    assert torch.isfinite(ws_a).all()
+    werr = (ws_a - ws_b).abs().max().item()          # sums over 16 rows of O(1) terms
+    assert werr < 2e-5 * max(1.0, ws_b.abs().max().item()), werr
+    assert (dx_a[:, :xoff] == 3).all() and (dx_a[:, xoff + n:] == 3).all()      # rows outside the map untouched
+    assert (dxb_a[:, :xoff] == 3).all() and (dxb_a[:, xoff + n:] == 3).all()
 
 
 # ----------------------------------------------------------------------------------------------- attention
