@@ -90,6 +90,27 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #ifndef MH_LN_FAST
 #define MH_LN_FAST 1      // -DMH_LN_FAST=0 (MH_BUILD_FLAGS) builds the library without the straight-line forms (A/B aid)
 #endif
+#ifndef MH_LN_DPP
+#define MH_LN_DPP 1
+#endif
+// Wave sum of the straight-line kernels (all 64 lanes active there).  MH_LN_DPP = 1 (default): each 16-lane row all-reduces by
+// four DPP rotations (row_ror:8, 4, 2, 1: one v_add_f32_dpp each, no LDS crossbar round trip), then the four row sums meet
+// through v_readlane.  With the loads no longer serialized the twelve ds_bpermute round trips per row show: forward -4 ... -7 %
+// per launch, backward -1 ... -9 % (profiles/r03_ln_straightline.txt); 0 keeps the shuffle butterfly of wave_sum (the sums then
+// differ from the generic kernels' in their last bits only by fma contraction; with 1 also by the order of the 64 partial sums).
+__device__ __forceinline__ float ln_wave_sum(float v) {
+#if MH_LN_DPP
+#define MH_ROR(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
+    v += MH_ROR(8); v += MH_ROR(4); v += MH_ROR(2); v += MH_ROR(1);
+#undef MH_ROR
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
+#else
+    return wave_sum(v);
+#endif
+}
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const float* __restrict__ x, RowMap xm, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, bf16_t* __restrict__ y, RowMap ym,
@@ -112,14 +133,14 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const float* __restric
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    const float mu = wave_sum(s) / dim;
+    const float mu = ln_wave_sum(s) / dim;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; }
     }
-    const float rs = rsqrtf(wave_sum(q) / dim + eps);
+    const float rs = rsqrtf(ln_wave_sum(q) / dim + eps);
     bf16_t* yr = y + map_row(ym, b, j) * dim;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -135,7 +156,10 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const float* __restric
 // Backward. Each wave walks ROWS_PER_WAVE rows keeping per-column partials of dgamma, dbeta and colsum(dx) in
 // registers; the block reduces them through LDS and writes ONE partial row [3*dim] to the workspace (plain stores);
 // ln_bwd_reduce_kernel then sums the partial rows (few atomics per column, no same-address storm).
-constexpr int ROWS_PER_WAVE = 4;  // 16 rows per block: >= 2 blocks per CU at M = 8192 (8 was bandwidth-starved: 256 blocks)
+#ifndef LN_ROWS
+#define LN_ROWS 4
+#endif
+constexpr int ROWS_PER_WAVE = LN_ROWS;  // 4: 16 rows per block, >= 2 blocks per CU at M = 8192 (8 was bandwidth-starved: 256 blocks)
 
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, RowMap dym, int dy_is_f32,
@@ -321,7 +345,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const bf16_t* __restri
                     bsum[i][e] += d[e];
                 }
             }
-            const float c1 = wave_sum(s1) / dim, c2 = wave_sum(s2) / dim;
+            const float c1 = ln_wave_sum(s1) / dim, c2 = ln_wave_sum(s2) / dim;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c4 = 4 * (lane + 64 * i);
@@ -463,8 +487,9 @@ static int layernorm_bwd_impl(const void* dy, int dy_L, int dy_off, int dy_is_f3
     const int nvs = ln_nv(dim);
     if (MH_LN_FAST && nvs <= 4 && dim == 256 * nvs && !dy_is_f32 && dres && dx_bf16 && rows % ROWS_PER_WAVE == 0) {
         // the transformer blocks' own case: straight-line kernel, all of a wave's rows in flight (two at dim 1024: registers)
-        switch (nvs) { case 1: LN_BWD_FAST(1, LN_BWD_DEPTH); break; case 2: LN_BWD_FAST(2, LN_BWD_DEPTH); break;
-                       case 3: LN_BWD_FAST(3, LN_BWD_DEPTH); break; default: LN_BWD_FAST(4, 2); }
+        constexpr int DEPTH = LN_BWD_DEPTH < ROWS_PER_WAVE ? LN_BWD_DEPTH : ROWS_PER_WAVE, DEPTH4 = 2 < ROWS_PER_WAVE ? 2 : ROWS_PER_WAVE;
+        switch (nvs) { case 1: LN_BWD_FAST(1, DEPTH); break; case 2: LN_BWD_FAST(2, DEPTH); break;
+                       case 3: LN_BWD_FAST(3, DEPTH); break; default: LN_BWD_FAST(4, DEPTH4); }
     } else {
         switch (nvs) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break;
                        case 4: LN_BWD(4); break; default: LN_BWD(8); }

@@ -81,7 +81,7 @@ def test_layernorm_straight_line_forms_equal_generic(dev, dim, B, n, xL, xoff, y
         a, b = a.float(), b.float()
         return bool(((a - b).abs() <= 2.0 ** -7 * b.abs() + 2e-5 * max(1.0, b.abs().max().item())).all())
     assert close16(ya, yb.bfloat16()) and (ya != yb.bfloat16()).float().mean() < 2e-2
-    assert torch.allclose(stats[0], stats[2], rtol=1e-6, atol=1e-7) and torch.allclose(stats[1], stats[3], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(stats[0], stats[2], rtol=1e-5, atol=1e-6) and torch.allclose(stats[1], stats[3], rtol=1e-5, atol=1e-6)
     dy = _rand(B, yL, dim, seed=14).to(dev).bfloat16()
     dres = _rand(B, xL, dim, seed=15).to(dev)
     n_ws = hip.layernorm_bwd_workspace(rows, dim)
