@@ -290,6 +290,7 @@ def main() -> None:
                             overlap_optimizer=args.overlap_optimizer, dtype=args.dtype)
     else:
         loop = SupervisedLoop(model, args.batch, dev, phase=args.phase, total_steps=args.steps + args.warmup, world_size=world)
+    warm_cfg = loop.engine.warm_passes     # start-up passes of the first step (engine.py: warm_passes; MAESTRO_WARM_PASSES)
     batch = synthetic_batch(ds.dataset, args.batch, dev, seed=rank)
     batch.update(synthetic_targets(ds.dataset, args.batch, dev, seed=rank))
     if args.single_stream:
@@ -379,7 +380,8 @@ def main() -> None:
                        "global_batch": args.batch * world, "loss": args.loss if args.phase == "pretrain" else "loss_pred",
                        "fusion_mode": "group", "inter_depth": 3,
                        "parallelism": f"dp{world}", "params_M": round(loop.engine.store.total / 1e6, 1),
-                       "final_loss": round(loss_val, 5), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3)},
+                       "final_loss": round(loss_val, 5), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
+                       "warm_passes": warm_cfg},
             "whole_step": {"train_gflop_per_tile": w["gflop_tile"],
                            "mfma_frac": round(value / world * w["gflop_tile"] / 1e3 / MFMA_PEAK_TFLOPS, 4)},
         }
@@ -404,7 +406,8 @@ def main() -> None:
                 if kern:
                     out["roofline"]["traffic"] = kern["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(traffic_file)} (rocprofv3 --pmc FETCH_SIZE / "
-                                                         "WRITE_SIZE passes of this command)")
+                                                         "WRITE_SIZE passes of this command), collected at commit "
+                                                         + str(json.load(open(traffic_file)).get("commit", "unrecorded")))
                 whole = json.load(open(traffic_file)).get("hbm_bytes_per_step")
                 if whole:   # every kernel's PMC bytes per launch x launches per step: the step's second bound next to mfma_frac
                     out["whole_step"]["hbm_gb_per_step"] = round(whole / 1e9, 1)

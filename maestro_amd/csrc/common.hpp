@@ -52,6 +52,21 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// Absmax bookkeeping of the fp8 path.  An absmax is held as a float whose BITS are compared as unsigned integers: on |x| the
+// integer order is the float order, with NaN (0x7fc00000 and up) above +inf above every finite value -- so a non-finite
+// element survives every fold, wave reduction and atomic max (fmaxf would drop a NaN and report a clean tensor) and reaches
+// mh_fp8_update_scales, which poisons the tensor's scale with it: the divergence shows in the loss instead of being clamped
+// to +-448 operands.
+__device__ __forceinline__ float amax_fold(float acc, float x) {
+    return __uint_as_float(max(__float_as_uint(acc), __float_as_uint(x) & 0x7fffffffu));
+}
+__device__ __forceinline__ float wave_amax(float v) {
+    uint32_t u = __float_as_uint(v);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) u = max(u, (uint32_t)__shfl_xor((int)u, o, 64));
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ bool amax_nonzero(float v) { return __float_as_uint(v) != 0u; }
 // Block-wide sum for blockDim.x = 64*NW threads; `red` is NW floats of LDS. Result broadcast to all threads.
 template <int NW>
 __device__ __forceinline__ float block_sum(float v, float* red) {

@@ -42,7 +42,14 @@ __device__ __forceinline__ u32x2 pack_fp8x8(f32x4 lo, f32x4 hi, float s, bool e5
     }
     return (u32x2){(uint32_t)a, (uint32_t)b};
 }
-// Fold an absmax (v >= 0: the int order of the bits is the float order) into a slot's amax ROW (MH_FP8_AMAX_PITCH floats).
+__device__ __forceinline__ uint32_t pack_e4m3x4(f32x4 v, float s) {   // 4 floats -> 4 saturating OCP e4m3 bytes
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e] * s, -448.f), 448.f);
+    int a = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    a = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], a, true);
+    return (uint32_t)a;
+}
+// Fold an absmax (v >= 0 or NaN: the int order of the bits is the float order, NaN on top: see amax_fold) into a slot's amax ROW (MH_FP8_AMAX_PITCH floats).
 // Atomics on one cache line retire at ~10 ns apiece whatever the address inside it (scripts/micro_amax.hip; a look-before-
 // you-add needs an agent-scope load to see other CUs' maxima at all -- plain and nontemporal loads are served stale -- and
 // still leaves the ~8000 waves resident at launch to storm the word: +80 us on a 7 us LayerNorm).  32 sub-slots 256 bytes
@@ -203,7 +210,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                     if (p.c8) {
                         *reinterpret_cast<u32x2*>(p.c8 + (size_t)m * p.ldc8 + n) = pack_fp8x8(lo, hi, s8, p.flags & MH_GEMM_C8_E5M2);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) amax8 = fmaxf(amax8, fmaxf(fabsf(lo[e]), fabsf(hi[e])));
+                        for (int e = 0; e < 4; ++e) amax8 = amax_fold(amax_fold(amax8, lo[e]), hi[e]);
                     }
                 }
             }
@@ -229,8 +236,8 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
         }
     }
     if (p.c8 && p.c8_amax) {
-        amax8 = wave_max(amax8);
-        if (l == 0 && amax8 > 0.f) atomic_max_pos(p.c8_amax, amax8);
+        amax8 = wave_amax(amax8);
+        if (l == 0 && amax_nonzero(amax8)) atomic_max_pos(p.c8_amax, amax8);
     }
 }
 

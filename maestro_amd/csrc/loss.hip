@@ -176,13 +176,10 @@ __device__ __forceinline__ int adamw_update(float* __restrict__ p, const float* 
         const int slot = f8.slot_map[i >> 6];
         if (slot >= 0) {
             const float s8 = f8.scale[slot];
-            f32x4 q8;
             float mx = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { mx = fmaxf(mx, fabsf(pv[e])); q8[e] = fminf(fmaxf(pv[e] * s8, -448.f), 448.f); }
-            int a = __builtin_amdgcn_cvt_pk_fp8_f32(q8[0], q8[1], 0, false);
-            a = __builtin_amdgcn_cvt_pk_fp8_f32(q8[2], q8[3], a, true);
-            *reinterpret_cast<uint32_t*>(f8.p8 + i) = (uint32_t)a;
+            for (int e = 0; e < 4; ++e) mx = amax_fold(mx, pv[e]);     // keeps inf / NaN (common.hpp)
+            *reinterpret_cast<uint32_t*>(f8.p8 + i) = pack_e4m3x4(pv, s8);
             *amax_out = mx;
             return slot;
         }
@@ -208,19 +205,19 @@ __global__ __launch_bounds__(256) void adamw_fp8_kernel(float* __restrict__ p, c
     const int slot0 = __builtin_amdgcn_readfirstlane(slot);      // first ACTIVE lane: all lanes are active here
     const bool uniform = __all(slot == slot0);
     if (uniform) {
-        mx = wave_max(mx);
-    } else if (slot >= 0 && mx > 0.f) {
+        mx = wave_amax(mx);
+    } else if (slot >= 0 && amax_nonzero(mx)) {
         atomic_max_pos(f8.amax + (size_t)slot * MH_FP8_AMAX_PITCH, mx);   // a wave across a tensor boundary: rare
     }
     if ((threadIdx.x & 63) == 0) { red_mx[w] = uniform ? mx : 0.f; red_slot[w] = uniform ? slot0 : -1; }
     __syncthreads();
     if (threadIdx.x == 0) {
         if (red_slot[0] == red_slot[1] && red_slot[0] == red_slot[2] && red_slot[0] == red_slot[3]) {
-            const float m4 = fmaxf(fmaxf(red_mx[0], red_mx[1]), fmaxf(red_mx[2], red_mx[3]));
-            if (red_slot[0] >= 0 && m4 > 0.f) atomic_max_pos(f8.amax + (size_t)red_slot[0] * MH_FP8_AMAX_PITCH, m4);
+            const float m4 = amax_fold(amax_fold(amax_fold(red_mx[0], red_mx[1]), red_mx[2]), red_mx[3]);
+            if (red_slot[0] >= 0 && amax_nonzero(m4)) atomic_max_pos(f8.amax + (size_t)red_slot[0] * MH_FP8_AMAX_PITCH, m4);
         } else {
             for (int k = 0; k < 4; ++k)
-                if (red_slot[k] >= 0 && red_mx[k] > 0.f) atomic_max_pos(f8.amax + (size_t)red_slot[k] * MH_FP8_AMAX_PITCH, red_mx[k]);
+                if (red_slot[k] >= 0 && amax_nonzero(red_mx[k])) atomic_max_pos(f8.amax + (size_t)red_slot[k] * MH_FP8_AMAX_PITCH, red_mx[k]);
         }
     }
 }

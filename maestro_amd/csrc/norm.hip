@@ -62,25 +62,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(y) + yrow + 4 * c) = pk;
             }
             if (y8) {
-                f32x4 q8;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    amax8 = fmaxf(amax8, fabsf(o[e]));
-                    q8[e] = fminf(fmaxf(o[e] * s8, -448.f), 448.f);
-                }
-                int a = __builtin_amdgcn_cvt_pk_fp8_f32(q8[0], q8[1], 0, false);
-                a = __builtin_amdgcn_cvt_pk_fp8_f32(q8[2], q8[3], a, true);
-                *reinterpret_cast<uint32_t*>(y8 + yrow + 4 * c) = (uint32_t)a;
+                for (int e = 0; e < 4; ++e) amax8 = amax_fold(amax8, o[e]);
+                *reinterpret_cast<uint32_t*>(y8 + yrow + 4 * c) = pack_e4m3x4(o, s8);
             }
         }
     }
     if (y8 && y8_amax) {
-        amax8 = wave_max(amax8);
-        if (lane == 0 && amax8 > 0.f) atomic_max_pos(y8_amax, amax8);
+        amax8 = wave_amax(amax8);
+        if (lane == 0 && amax_nonzero(amax8)) atomic_max_pos(y8_amax, amax8);
     }
 }
 
-// Straight-line forward for the step's own case (dim == 256 * NV: every lane holds NV float4; bf16 output, no e4m3 copy).
+// Straight-line forward for the step's own case (dim == 256 * NV: every lane holds NV float4; bf16 output, optional e4m3 copy).
 // Same operations in the same order as ln_fwd_kernel (results equal up to the compiler's fma contraction: a few fp32 ulp,
 // tests/test_kernels_gpu.py), but no lane predicates and no output-type branches, so that the code is ONE scheduling region.  In the generic kernel's ISA (gfx950, -O3) every predicated chunk
 // ends in `s_waitcnt vmcnt(0)`: the row's NV loads went out as NV dependent round trips, gamma / beta were fetched after
@@ -111,11 +105,14 @@ __device__ __forceinline__ float ln_wave_sum(float v) {
     return wave_sum(v);
 #endif
 }
-template <int NV>
+// FP8 = true (mh_layernorm_fwd_fp8): the same kernel also writes the e4m3 copy of the output (the next GEMM's A operand) and
+// folds |y| into the tensor's amax row; the bf16 output is the SAME instruction sequence, hence bit-identical to FP8 = false.
+template <int NV, bool FP8>
 __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const float* __restrict__ x, RowMap xm, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, bf16_t* __restrict__ y, RowMap ym,
                                                           float* __restrict__ mean, float* __restrict__ rstd, int B, int n,
-                                                          float eps) {
+                                                          float eps, uint8_t* __restrict__ y8, const float* __restrict__ y8_scale,
+                                                          float* __restrict__ y8_amax) {
     constexpr int dim = 256 * NV;
     const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -141,7 +138,11 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const float* __restric
         for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; }
     }
     const float rs = rsqrtf(ln_wave_sum(q) / dim + eps);
-    bf16_t* yr = y + map_row(ym, b, j) * dim;
+    const size_t yrow = map_row(ym, b, j) * dim;
+    bf16_t* yr = y + yrow;
+    float s8 = 0.f;
+    if constexpr (FP8) s8 = *y8_scale;
+    float amax8 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         f32x4 o;
@@ -149,8 +150,19 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const float* __restric
         for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[i][e] + bt[i][e];
         const u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
         *reinterpret_cast<u32x2*>(yr + 4 * (lane + 64 * i)) = pk;
+        if constexpr (FP8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax8 = amax_fold(amax8, o[e]);
+            *reinterpret_cast<uint32_t*>(y8 + yrow + 4 * (lane + 64 * i)) = pack_e4m3x4(o, s8);
+        }
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    if constexpr (FP8) {
+        if (y8_amax) {
+            amax8 = wave_amax(amax8);
+            if (lane == 0 && amax_nonzero(amax8)) atomic_max_pos(y8_amax, amax8);
+        }
+    }
 }
 
 // Backward. Each wave walks ROWS_PER_WAVE rows keeping per-column partials of dgamma, dbeta and colsum(dx) in
@@ -450,10 +462,11 @@ static int layernorm_fwd_impl(const float* x, int x_L, int x_off, const float* g
     hipStream_t s = (hipStream_t)stream;
 #define LN_FWD(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, grid, block, 0, s, x, RowMap{x_L, x_off}, gamma, beta, y, \
                                       RowMap{y_L, y_off}, y_is_f32, mean, rstd, B, n, dim, eps, (uint8_t*)y8, y8_scale, y8_amax)
-#define LN_FWD_FAST(NV) hipLaunchKernelGGL(ln_fwd_fast_kernel<NV>, grid, block, 0, s, x, RowMap{x_L, x_off}, gamma, beta, \
-                                           (bf16_t*)y, RowMap{y_L, y_off}, mean, rstd, B, n, eps)
+#define LN_FWD_FAST_(NV, FP8) hipLaunchKernelGGL((ln_fwd_fast_kernel<NV, FP8>), grid, block, 0, s, x, RowMap{x_L, x_off}, gamma, beta, \
+                                                 (bf16_t*)y, RowMap{y_L, y_off}, mean, rstd, B, n, eps, (uint8_t*)y8, y8_scale, y8_amax)
+#define LN_FWD_FAST(NV) do { if (y8) LN_FWD_FAST_(NV, true); else LN_FWD_FAST_(NV, false); } while (0)
     const int nvs = ln_nv(dim);
-    if (MH_LN_FAST && nvs <= 4 && dim == 256 * nvs && !y_is_f32 && !y8) {     // the step's own case: straight-line kernel
+    if (MH_LN_FAST && nvs <= 4 && dim == 256 * nvs && !y_is_f32) {     // the step's own case: straight-line kernel (with or without the e4m3 copy)
         switch (nvs) { case 1: LN_FWD_FAST(1); break; case 2: LN_FWD_FAST(2); break; case 3: LN_FWD_FAST(3); break;
                        default: LN_FWD_FAST(4); }
     } else {
@@ -461,6 +474,7 @@ static int layernorm_fwd_impl(const float* x, int x_L, int x_off, const float* g
                        case 4: LN_FWD(4); break; default: LN_FWD(8); }
     }
 #undef LN_FWD_FAST
+#undef LN_FWD_FAST_
 #undef LN_FWD
     MH_LAUNCH_CHECK();
     return 0;

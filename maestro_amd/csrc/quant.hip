@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void quant_batched_kernel(const MhQuantJob* __
         const long i = base + r * 1024 + threadIdx.x * 4;
         if (i < jb.n) {   // n % 4 == 0
             const f32x4 v = load4(jb.src, jb.is_f32, i);
-            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            mx = amax_fold(amax_fold(amax_fold(amax_fold(mx, v[0]), v[1]), v[2]), v[3]);
             if (mode != 0) {
                 const uint32_t pk = pack_fp8x4(v, s, jb.format == MH_FP8_E5M2);
                 if (jb.dst) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(jb.dst) + i) = pk;
@@ -63,23 +63,23 @@ __global__ __launch_bounds__(256) void quant_batched_kernel(const MhQuantJob* __
         }
     }
     if (mode != 1) {   // 0: absmax only; 2: cast + absmax (delayed scaling); 1: cast only
-        mx = wave_max(mx);
+        mx = wave_amax(mx);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
         __syncthreads();
         if (threadIdx.x == 0) {
-            mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-            if (mx > 0.f) atomic_max_pos(amax + (size_t)jb.slot * MH_FP8_AMAX_PITCH, mx);
+            mx = amax_fold(amax_fold(amax_fold(red[0], red[1]), red[2]), red[3]);
+            if (amax_nonzero(mx)) atomic_max_pos(amax + (size_t)jb.slot * MH_FP8_AMAX_PITCH, mx);
         }
     }
 }
 
-// scale = 2^(floor(log2(fmax / amax)) - margin) (1 while amax is 0 or not finite), descale = 1 / scale, amax reset to 0
+// scale = 2^(floor(log2(fmax / amax)) - margin) (1 while amax is 0; NaN when amax is inf / NaN: the divergence must show), descale = 1 / scale, amax reset to 0
 __global__ __launch_bounds__(256) void update_scales_kernel(float* __restrict__ amax, float* __restrict__ scale,
                                                             float* __restrict__ descale, int n, float fmax8, int margin) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;   // one wave per slot: maximum over its amax row
     if (i >= n) return;
     float* row = amax + (size_t)i * MH_FP8_AMAX_PITCH + (l & (MH_FP8_AMAX_SUBSLOTS - 1)) * MH_FP8_AMAX_STRIDE;
-    const float a = wave_max(*row);
+    const float a = wave_amax(*row);
     if (l < MH_FP8_AMAX_SUBSLOTS) *row = 0.f;
     if (l != 0) return;
     float s = 1.f;
@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256) void update_scales_kernel(float* __restrict__ 
         int e = (int)floorf(log2f(fmax8 / a)) - margin;
         e = max(-100, min(100, e));
         s = exp2f((float)e);
+    } else if (amax_nonzero(a)) {
+        s = __uint_as_float(0x7fc00000u);     // the tensor held an inf / NaN: poison its scale and descale -> NaN GEMM outputs, NaN loss
     }
     scale[i] = s;
     descale[i] = 1.f / s;

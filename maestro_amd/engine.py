@@ -517,6 +517,11 @@ class StackSet:
 _RETIRED_GRAPHS: list = []
 
 
+def training_warm_passes() -> int:
+    """Start-up passes a TRAINING entry point asks its engine for (see ``EngineBase.warm_passes``)."""
+    return 0 if _PROCESS_WARMED else max(0, int(os.environ.get("MAESTRO_WARM_PASSES", "6")))
+
+
 def _retire_graphs(graphs: dict) -> None:      # weakref.finalize callback: must not reference the engine
     if graphs:
         _RETIRED_GRAPHS.append(dict(graphs))
@@ -524,10 +529,17 @@ def _retire_graphs(graphs: dict) -> None:      # weakref.finalize callback: must
 
 
 def drain_retired_graphs() -> None:
-    """Destroy the hipGraphs of engines that no longer exist, with the device idle.  NOT called automatically: see below."""
+    """Destroy the hipGraphs (and release the private memory pools) of engines that no longer exist, with the device idle.
+    Called by every engine's constructor -- the safe point: nothing of the new engine is in flight yet -- so a process that
+    rebuilds its engine (a partial last batch, validation at another batch size: ``ssl/mae.py``) does not accumulate the dead
+    engines' pools; ``MAESTRO_KEEP_RETIRED_GRAPHS=1`` leaves them alive (diagnostic)."""
     if _RETIRED_GRAPHS:
         torch.cuda.synchronize()
         _RETIRED_GRAPHS.clear()
+
+
+# The start-up passes (``EngineBase.warm_passes``) answer a per-PROCESS effect: only the first engine that asks for them runs them.
+_PROCESS_WARMED = False
 
 
 class EngineBase:
@@ -561,13 +573,17 @@ class EngineBase:
         self.instep_tune = (os.environ.get("MAESTRO_INSTEP_TUNE", "0") == "1" and not self.tune_gemm
                             and not any(os.environ.get(k) for k in ("MH_GEMM_TILE", "MH_GEMM_DMA", "MH_GEMM_PP", "MH_DMA_STAGGER")))
         self.tile_report = None     # {signature: (picked tile, {candidate: ms})} of this engine's tuning passes
-        # MAESTRO_WARM_PASSES (default 6): the first step recomputes its own forward + backward that many extra times (same inputs,
-        # same draws, no optimizer update, no gradient exchange) before it runs for real.  On this platform some of the first ~8
-        # steps of a process run their forward ~1 ms (15 %) slower whatever the launch mode (graphs or eager, one stream or
-        # several: scripts/step_phases.py) -- a start-up effect of ~100-150 ms of load that would otherwise sit in the first
-        # optimizer steps of every run.  Results are unchanged (the passes overwrite the same buffers with the same values);
-        # not with fp8 (amax history) or an optimizer captured into the forward.  0 disables.
-        self.warm_passes = int(os.environ.get("MAESTRO_WARM_PASSES", "6"))
+        # Start-up passes, OPT-IN (0 = off, the default of a bare engine: an eval-only / validation / predict caller must never
+        # get backward launches, backward workspaces or a zeroed gradient buffer from a forward).  With n > 0 the first TRAINING
+        # step recomputes its own forward + backward n extra times (same inputs, same draws, no optimizer update, no gradient
+        # exchange) before it runs for real.  On this platform some of the first ~8 steps of a process run their forward ~1 ms
+        # (15 %) slower whatever the launch mode (graphs or eager, one stream or several: scripts/step_phases.py) -- a start-up
+        # effect of ~100-150 ms of load that would otherwise sit in the first optimizer steps of every run.  Results are
+        # unchanged (the passes overwrite the same buffers with the same values); not with fp8 (amax history) or an optimizer
+        # captured into the forward.  Who sets it: the explicit training loops (``PretrainLoop`` / ``SupervisedLoop``:
+        # ``MAESTRO_WARM_PASSES``, default 6, first engine of the process only); the Lightning surface never does.  bench.py
+        # reports the value in its JSON line (``config.warm_passes``).
+        self.warm_passes = 0
         # the GELU derivative saved by the fc1 epilogue for the backward: one byte per element (MH_GEMM_AUX_U8, step 0.005 on
         # [-0.129, 1.129]) instead of bf16 -- 1.7 GB less HBM traffic per C3 step; MAESTRO_AUX_U8=0 keeps bf16
         self.aux_flag = hip.AUX_U8 if os.environ.get("MAESTRO_AUX_U8", "1") == "1" else 0
@@ -576,6 +592,8 @@ class EngineBase:
         # collector's own timing they would die somewhere inside this engine's steps --, then destroy their graphs with the
         # device idle.
         gc.collect()
+        if os.environ.get("MAESTRO_KEEP_RETIRED_GRAPHS", "0") != "1":
+            drain_retired_graphs()
         self._graphs, self._seen, self._ready_spans = {}, {}, []
         weakref.finalize(self, _retire_graphs, self._graphs)
         self._inputs = {}           # per batch key: last device address, or the engine-owned staging copy
@@ -653,10 +671,12 @@ class EngineBase:
 
     def _warm_up(self, one_pass) -> None:
         """``one_pass()``: forward + zero_grad + backward of the current step (same inputs, same draws); see ``warm_passes``."""
+        global _PROCESS_WARMED
         n, self.warm_passes = self.warm_passes, 0
-        if (n <= 0 or getattr(self, "fp8", None) is not None or getattr(self, "_opt", None) is not None
-                or hip.kernel_timer_active() or torch.cuda.is_current_stream_capturing()):
+        if (n <= 0 or _PROCESS_WARMED or getattr(self, "fp8", None) is not None or getattr(self, "_opt", None) is not None
+                or hip.kernel_timer_active() or torch.cuda.is_current_stream_capturing() or not torch.is_grad_enabled()):
             return
+        _PROCESS_WARMED = True
         # eager launches: nothing is captured here (an engine that only ever runs one step -- most tests -- owns no hipGraph)
         hook, graphs = self.grad_hook, self.use_graphs
         self.use_graphs = False

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import torch
 
+from maestro_amd.engine import training_warm_passes
 from maestro_amd.train.ddp import GradSync, broadcast_parameters
 from maestro_amd.train.optim import FusedAdamW, OneCycle, scaled_lr
 
@@ -34,6 +35,7 @@ class PretrainLoop:
                  final_factor: float = 1e7, bucket_mb: int = 64, exchange: bool | None = None,
                  accumulate: int = 1, overlap_optimizer: bool = False, bucket_dtype=None, dtype: str | None = None) -> None:
         self.engine = model.engine(batch_size, device, loss=loss, dtype=dtype)
+        self.engine.warm_passes = training_warm_passes()     # a training entry point: start-up passes on (engine.py: warm_passes)
         if overlap_optimizer and self.engine.fp8 is not None:
             raise ValueError("overlap_optimizer is not available with dtype='fp8' (the e4m3 weight shadows are rebuilt after the update)")
         broadcast_parameters(self.engine)   # every rank starts from rank 0's weights (what Lightning's DDP wrap does)
@@ -144,6 +146,7 @@ class SupervisedLoop:
                  weight_decay: float = 0.01, total_steps: int = 1000, world_size: int = 1, final_factor: float = 1e7,
                  bucket_mb: int = 64, exchange: bool | None = None, bucket_dtype=None) -> None:
         self.engine = model.sup_engine(batch_size, device, phase)
+        self.engine.warm_passes = training_warm_passes()
         broadcast_parameters(self.engine)
         lr = scaled_lr(base_lr, batch_size, 1, 1, world_size)
         self.sched = OneCycle(lr, max(total_steps, 2), pct_start=0.2, div_factor=1000.0,

@@ -59,7 +59,11 @@ for k, v in agg.items():
               "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
 PMC_STEPS = 5   # profile_round.sh runs the counter passes with --steps 2 --warmup 3
 per_step = sum(v["hbm_bytes_per_launch"] * v["launches_in_trace"] for v in out.values()) / PMC_STEPS
+import subprocess
+head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip() or "unknown"
+dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "maestro_amd", "bench.py"], cwd=root, capture_output=True, text=True).stdout.strip())
 json.dump({"note": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE correction applied", "steps_in_trace": PMC_STEPS,
+           "commit": head + ("+uncommitted changes" if dirty else ""),
            "hbm_bytes_per_step": int(per_step), "kernels": out},
           open(dst / f"{tag}_hbm_traffic.json", "w"), indent=1, sort_keys=True)
 rows = list(csv.DictReader(open(src / f"{tag}_kernel_stats.csv")))

@@ -205,13 +205,14 @@ def test_engine_fp8_forward_matches_oracle(dev, observed, monkeypatch, dgrad):
     assert e3 < 1.2e-2, (loss3.item(), oloss3.item())     # observed 4.0e-3 (the first Adam step leaves the net at loss 6.5)
 
 
-def test_layernorm_fp8_output(dev):
-    """``mh_layernorm_fwd_fp8``: the bf16 output is the plain kernel's, the e4m3 copy is the cast of the fp32 value times the
+@pytest.mark.parametrize("M,dim", [(333, 768), (64, 256), (130, 512), (257, 1024), (100, 384), (50, 192), (7, 2048)])
+def test_layernorm_fp8_output(dev, M, dim):  # noqa: N803
+    """``mh_layernorm_fwd_fp8``: the bf16 output is the plain kernel's BIT FOR BIT (both entry points run the same kernel: the
+    straight-line one at dim = 256 k <= 1024, the generic one elsewhere), the e4m3 copy is the cast of the fp32 value times the
     scale (checked against torch's conversion of an fp32 LayerNorm: equal codes but for roundings of values that sit on a code
     boundary within fp32 noise), absmax recorded."""
     from maestro_amd import hip
     g = torch.Generator().manual_seed(2)
-    M, dim = 333, 768  # noqa: N806
     x = (torch.randn(M, dim, generator=g) * 3 + 0.5).to(dev)
     gamma, beta = (1 + 0.2 * torch.randn(dim, generator=g)).to(dev), (0.1 * torch.randn(dim, generator=g)).to(dev)
     y, y2 = torch.empty(M, dim, dtype=torch.bfloat16, device=dev), torch.empty(M, dim, dtype=torch.bfloat16, device=dev)
@@ -227,6 +228,55 @@ def test_layernorm_fp8_output(dev):
     diff = (y8.cpu().int() - want).abs()
     assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 2e-3
     assert abs(float(amax.max()) - float(ref.abs().max())) < 1e-4 * float(ref.abs().max())
+
+
+def test_non_finite_values_poison_the_scale(dev):
+    """A NaN / inf in a tensor must not vanish in the fp8 bookkeeping (the saturating cast turns it into +-448 and ``fmaxf`` would
+    drop it from the absmax): every absmax fold keeps it (integer order on |x| bits, NaN on top), ``mh_fp8_update_scales`` turns
+    it into a NaN scale / descale, and the next GEMM's descale makes the loss NaN -- as the bf16 path would show it.  Covers the
+    batched quantiser, the LayerNorm's e4m3 output (straight-line and generic kernel) and the fused AdamW's shadow refresh."""
+    import math
+    from maestro_amd import hip
+    g = torch.Generator().manual_seed(4)
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        # batched quantiser, absmax-only and cast + absmax
+        x = torch.randn(130, 64, generator=g)
+        x[77, 13] = bad
+        for mode in (0, 2):
+            sc = hip.Fp8Scales(2, dev)
+            dst = torch.zeros(x.shape, dtype=torch.uint8, device=dev)
+            hip.QuantBatch([dict(src=x.to(dev), dst=dst, slot=1, format=0)], sc, dev).launch(mode)
+            torch.cuda.synchronize()
+            a = sc.absmax(1)
+            assert (math.isnan(a) if math.isnan(bad) else a == float("inf")) and sc.absmax(0) == 0.0, (bad, mode, a)
+            sc.update(fmt=0, margin=1)
+            torch.cuda.synchronize()
+            assert math.isnan(float(sc.scale[1])) and math.isnan(float(sc.descale[1])), (bad, mode)
+            assert float(sc.scale[0]) == 1.0 and sc.absmax(1) == 0.0       # clean slots untouched, the row reset
+        # LayerNorm with the e4m3 copy: a non-finite input row gives a NaN output row -> the slot's absmax is NaN
+        for M, dim in ((64, 768), (33, 384)):  # noqa: N806
+            xx = torch.randn(M, dim, generator=g).to(dev)
+            xx[M // 2, 5] = bad
+            gamma, beta = torch.ones(dim, device=dev), torch.zeros(dim, device=dev)
+            y, y8 = torch.empty(M, dim, dtype=torch.bfloat16, device=dev), torch.zeros(M, dim, dtype=torch.uint8, device=dev)
+            mean, rstd = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+            sc = hip.Fp8Scales(1, dev)
+            hip.layernorm_fwd_fp8(xx, M, 0, gamma, beta, y, M, 0, mean, rstd, 1, M, dim, y8, sc.scale[0:1], sc.amax[0])
+            torch.cuda.synchronize()
+            assert math.isnan(sc.absmax(0)), (bad, dim, sc.absmax(0))
+            assert bool(torch.isfinite(y.float()[: M // 2]).all())          # the other rows are clean
+    # fused AdamW: a NaN gradient makes the updated weight NaN; the weight's slot must report it
+    n = 64 * 8
+    p, m, v = torch.randn(n, generator=g).to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    grad = torch.randn(n, generator=g)
+    grad[200] = float("nan")
+    half, p8 = torch.zeros(n, dtype=torch.bfloat16, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)
+    slot_map = torch.zeros(n // 64, dtype=torch.int16)
+    slot_map[4:] = 1
+    scale, amax = torch.tensor([64.0, 64.0], device=dev), torch.zeros(2, hip.AMAX_PITCH, device=dev)
+    hip.adamw_fp8(p, grad.to(dev), m, v, half, p8, slot_map.to(dev), scale, amax, n, 1e-3, 0.9, 0.99, 1e-8, 0.01, 1)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(amax[0]).any()) and not bool(torch.isnan(amax[1]).any())
 
 
 def test_adamw_fp8_refreshes_the_shadows_in_its_own_pass(dev):

@@ -43,7 +43,9 @@ def test_lds_fits_a_cu_and_workgroups_fit_their_registers(kernels):
 def test_straight_line_layernorm_kernels_are_in_the_library(kernels):
     names = {k["kernel"]: k for k in kernels}
     for nv in (1, 2, 3, 4):
-        assert f"ln_fwd_fast_kernel<{nv}>" in names
+        for fp8 in ("false", "true"):       # with and without the e4m3 copy (mh_layernorm_fwd_fp8): one kernel, two instantiations
+            form = f"ln_fwd_fast_kernel<{nv}, {fp8}>"
+            assert form in names and names[form]["private_segment_fixed_size"] == 0, form
     for form in ("ln_bwd_fast_kernel<1, 4>", "ln_bwd_fast_kernel<2, 4>", "ln_bwd_fast_kernel<3, 4>", "ln_bwd_fast_kernel<4, 2>"):
         assert form in names and names[form]["vgpr_count"] <= 256 and names[form]["private_segment_fixed_size"] == 0, form
 
@@ -90,8 +92,9 @@ def test_straight_line_kernels_issue_their_loads_before_the_first_wait():
     assert _loads_before_first_vm_wait(body_of("ln_bwd_fast_kernelILi3ELi4E")) >= 39
     assert _loads_before_first_vm_wait(body_of("ln_bwd_fast_kernelILi2ELi4E")) >= 26
     # forward: the whole row (and at least part of gamma / beta) before the first wait
-    assert _loads_before_first_vm_wait(body_of("ln_fwd_fast_kernelILi3E")) >= 3
-    assert _loads_before_first_vm_wait(body_of("ln_fwd_fast_kernelILi2E")) >= 2
+    for fp8 in ("Lb0E", "Lb1E"):
+        assert _loads_before_first_vm_wait(body_of("ln_fwd_fast_kernelILi3E" + fp8)) >= 3
+        assert _loads_before_first_vm_wait(body_of("ln_fwd_fast_kernelILi2E" + fp8)) >= 2
     # batched column sums: the chunk's 16 row loads together
     assert _loads_before_first_vm_wait(body_of("colsum_batched_kernel")) >= 16
     # and the generic backward still shows the pattern the straight-line form removes (documents the finding; if a compiler
