@@ -79,10 +79,7 @@ enum { MH_TILE_AUTO = -1, MH_TILE_REG_128 = 0, MH_TILE_DMA_256 = 1, MH_TILE_DMA_
        MH_TILE_PP_128_DIAG4 = 11, MH_TILE_PP_128_DIAG5 = 12,  /* full epilogue, other instruction placements */
        /* MH_TILE_REG_128's kernel with 64 x 128 tiles (three workgroups per CU) / 192 x 128 tiles: for outputs whose 128 x 128
         * tiling fills the chip's workgroup slots badly (N = 512 / 768).  NT / NN without MH_GEMM_COLSUM; otherwise = REG_128. */
-       MH_TILE_REG_64 = 13, MH_TILE_REG_192 = 14,
-       /* EXPERIMENTAL (gemm_m32.hip; not yet run on hardware, never picked by MH_TILE_AUTO): MH_TILE_REG_128's tile on
-        * v_mfma_f32_32x32x16_bf16.  NT, K %% 64 == 0, K >= 128, bf16 output, flags within BIAS | GELU | AUX_DGELU | AUX_U8; else -2. */
-       MH_TILE_M32_128 = 15 };
+       MH_TILE_REG_64 = 13, MH_TILE_REG_192 = 14 };
 int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                       int ldaux, float* colsum, void* stream);

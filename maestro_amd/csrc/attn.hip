@@ -24,13 +24,6 @@ constexpr float LOG2E = 1.4426950408889634f;
 #endif
 // ATTN_DIAG (diagnostic builds only, WRONG results; MH_ATTN_FLAGS="-DATTN_DIAG=n"): what is one VALU issue slot per score worth?
 //   bit 0: forward without the row-sum adds;  bit 1: backward without the scale / lse FMA and without the "- delta" add
-// ATTN_LAZY_RESCALE (opt-in, MH_ATTN_FLAGS="-DATTN_LAZY_RESCALE=1"; written at the end of round 3 from the loop's instruction mix,
-// NOT yet measured): the forward rescales its output accumulators by exp2((m_old - m_new) c) in every key tile -- 16 of the ~200 VALU
-// instructions per tile at D = 32.  Once the running maximum has stopped moving for every row of the wave the factor is exactly 1.0
-// and the multiplies are skipped under a wave-uniform test: bit-identical results (x * 1.0f == x).
-#ifndef ATTN_LAZY_RESCALE
-#define ATTN_LAZY_RESCALE 0
-#endif
 #ifndef ATTN_DIAG
 #define ATTN_DIAG 0
 #endif
@@ -252,13 +245,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             const float ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
 #endif
             lsum[qt] = lsum[qt] * alpha + ps;
-#if ATTN_LAZY_RESCALE
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0)
-#endif
-            {
+            // (skipping these multiplies under a wave-uniform `alpha == 1` test -- bit-identical, 9 % fewer VALU instructions on tiles
+            //  whose maximum did not move -- measured no gain: profiles/r04_experiments.txt)
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) o[qt][dt] = scale4(o[qt][dt], alpha);
-            }
+            for (int dt = 0; dt < DT; ++dt) o[qt][dt] = scale4(o[qt][dt], alpha);
             pf[qt][0] = pack_acc(s[qt][0], s[qt][1]);
             pf[qt][1] = pack_acc(s[qt][2], s[qt][3]);
         }

@@ -203,10 +203,6 @@ __global__ __launch_bounds__(NT, MT == 2 ? 3 : 2) void gemm_kernel(GemmParams p)
 // efficiency: the M = 32768 decoder shapes); it loses when the tile count quantises badly (M = 8192 encoder shapes) and for
 // split-K wgrads (more splits -> more fp32 atomic passes).  The library reads no environment: a caller that wants another
 // kernel passes an explicit tile to mh_gemm_bf16_tile (maestro_amd/hip.py maps MH_GEMM_DMA / MH_GEMM_TILE onto that).
-// gemm_m32.hip (experimental; tile = MH_TILE_M32_128); -2 = not eligible
-int gemm_m32_dispatch(int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int flags,
-                      const float* bias, void* aux_out, int ldaux, void* stream);
-
 static bool prefer_dma(int layout, int M, int N, int K, int flags) {
     if (layout == 2 || (flags & MH_GEMM_ATOMIC) || K % 32 != 0 || K < 256) return false;
     const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256);
@@ -218,7 +214,7 @@ static bool prefer_dma(int layout, int M, int N, int K, int flags) {
 extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                                  void* C, int ldc, int flags, const float* bias, const float* res, int ldr,
                                  const void* aux_in, void* aux_out, int ldaux, float* colsum, void* stream) {
-    MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_M32_128, "mh_gemm_bf16: tile %d", tile);
+    MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_REG_192, "mh_gemm_bf16: tile %d", tile);
     MH_CHECK_ARG(layout >= 0 && layout <= 2, "mh_gemm_bf16: layout %d", layout);
     MH_CHECK_ARG(M > 0 && N > 0 && K > 0, "mh_gemm_bf16: empty problem %d %d %d", M, N, K);
     MH_CHECK_ARG(A && B && C, "mh_gemm_bf16: null operand");
@@ -247,8 +243,6 @@ extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, cons
     MH_CHECK_ARG(!(flags & MH_GEMM_ATOMIC) || !(flags & ~(MH_GEMM_ATOMIC | MH_GEMM_OUT_F32)),
                  "mh_gemm_bf16: atomic accumulate excludes other epilogues");
 
-    if (tile == MH_TILE_M32_128)      // experimental 32x32x16 form (gemm_m32.hip): explicit tile only; -2 when not eligible
-        return gemm_m32_dispatch(layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, aux_out, ldaux, stream);
     if (tile >= MH_TILE_PP_128 && tile <= MH_TILE_PP_128_DIAG5)
         return gemm_pp_dispatch(layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, stream,
                                 tile - MH_TILE_PP_128);

@@ -63,14 +63,13 @@ TILE_AUTO, TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_
 TILE_DMA_256_LOCKSTEP = 6   # MH_TILE_DMA_256 without the wave-group stagger (A/B experiments)
 TILE_REG_64, TILE_REG_192 = 13, 14   # the register-staged kernel with 64 x 128 / 192 x 128 tiles
 TILE_PP_128 = 7             # persistent 128x128 tile, epilogue of tile t inside the main loop of tile t + 1 (gemm_pp.hip)
-TILE_M32_128 = 15           # EXPERIMENTAL (gemm_m32.hip, not yet run on hardware): the 128x128 NT tile on 32x32x16 MFMAs; explicit only
 TILES = (TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128, TILE_DMA_128x4)
 _LAYOUT_NAME = {0: "NT", 1: "NN", 2: "TN"}
 _TILE_NAME = {TILE_REG_128: "gemm_kernel<{}>", TILE_DMA_256: "gemm_dma_kernel<256x256,{}>",
               TILE_DMA_256x128: "gemm_dma_kernel<256x128,{}>", TILE_DMA_128x256: "gemm_dma_kernel<128x256,{}>",
               TILE_DMA_128: "gemm_dma_kernel<128x128,{}>", TILE_DMA_128x4: "gemm_dma_kernel<128x128q,{}>",
               TILE_DMA_256_LOCKSTEP: "gemm_dma_kernel<256x256,{}>", TILE_PP_128: "gemm_pp_kernel<{}>",
-              TILE_REG_64: "gemm_kernel<{},64x128>", TILE_REG_192: "gemm_kernel<{},192x128>", TILE_M32_128: "gemm_m32_kernel<{}>"}
+              TILE_REG_64: "gemm_kernel<{},64x128>", TILE_REG_192: "gemm_kernel<{},192x128>"}
 _tile_choice: dict = {}     # (layout, M, N, K, flags) -> fastest tile, filled while tuning is on
 _tuning = False
 

@@ -18,14 +18,13 @@ def pytest_configure(config):
 
 # Run order of the GPU suite (the driver runs ``pytest -m gpu -x``: a stop must not hide core parity behind an opt-in feature).
 # Core parity first -- the bench configuration, the full-width BASELINE configurations, the reference-generated goldens --, then
-# the kernel-level tests, then the wider rows (supervised branch, staging, data parallel), and the opt-in paths (fp8, experimental
-# tiles) last.  Files not listed keep their alphabetical place between the kernel tests and the opt-in group.
+# the kernel-level tests, then the wider rows (supervised branch, staging, data parallel), and the opt-in paths (fp8) last.  Files not listed keep their alphabetical place between the kernel tests and the opt-in group.
 _GPU_ORDER = [
     "test_bench_config_parity_gpu", "test_fullwidth_parity_gpu", "test_mae_gpu",
     "test_kernels_gpu", "test_gemm_gpu", "test_gemm_dma_gpu", "test_gemm_grouped_gpu", "test_heads_gpu",
     "test_sup_gpu", "test_staging_gpu", "test_fullsize_gpu", "test_abi_cpp_gpu", "test_ddp_gpu", "test_ddp_nccl_gpu",
 ]
-_GPU_LAST = ["test_fp8_gpu", "test_gemm_m32_gpu"]
+_GPU_LAST = ["test_fp8_gpu"]
 
 
 def pytest_collection_modifyitems(session, config, items):
