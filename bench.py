@@ -249,6 +249,10 @@ def main() -> None:
     ap.add_argument("--rehearse-dry", action="store_true",
                     help="the same launch plan (gradient hooks, backward segments, two-part AdamW) without a process group: what the "
                          "plan itself costs, without RCCL's one-rank self-copies")
+    ap.add_argument("--exchange-mode", default=None, choices=["all_reduce", "rs_ag"],
+                    help="gradient exchange at N > 1: all-reduce per bucket (default) or reduce-scatter -> sharded AdamW -> all-gather")
+    ap.add_argument("--log-losses", action="store_true",
+                    help="diagnostic: add the loss of every timed step to the JSON line (one tiny device copy per step)")
     ap.add_argument("--shapes", action="store_true", help="print per-shape kernel times to stderr (diagnostic)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -287,7 +291,7 @@ def main() -> None:
     if args.phase == "pretrain":
         loop = PretrainLoop(model, args.batch, dev, loss=args.loss, total_steps=args.steps + args.warmup, world_size=world,
                             exchange=True if (args.rehearse_exchange or args.rehearse_dry) else None,
-                            overlap_optimizer=args.overlap_optimizer, dtype=args.dtype)
+                            overlap_optimizer=args.overlap_optimizer, dtype=args.dtype, exchange_mode=args.exchange_mode)
     else:
         loop = SupervisedLoop(model, args.batch, dev, phase=args.phase, total_steps=args.steps + args.warmup, world_size=world)
     warm_cfg = loop.engine.warm_passes     # start-up passes of the first step (engine.py: warm_passes; MAESTRO_WARM_PASSES)
@@ -325,12 +329,15 @@ def main() -> None:
     sync()
     wait0 = getattr(loop.engine, "host_wait_s", 0.0)
     t0 = time.perf_counter()
+    loss_log = []
     marks = []                # one event per step boundary: per-step GPU times (min / median) without any host sync
     for _ in range(args.steps):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         marks.append(ev)
         loss = loop.step(batch)
+        if args.log_losses:
+            loss_log.append(loss.detach().clone())
     flush()   # the K-th optimizer update belongs to the timed region: K forwards, K backwards, K AdamW updates
     # host time spent ISSUING the steps (diagnostic: host-bound if ~= elapsed): the time blocked on the mask staging
     # ring's back-pressure (host >= 4 steps ahead of the GPU) is not issue work and is taken out
@@ -381,10 +388,13 @@ def main() -> None:
                        "fusion_mode": "group", "inter_depth": 3,
                        "parallelism": f"dp{world}", "params_M": round(loop.engine.store.total / 1e6, 1),
                        "final_loss": round(loss_val, 5), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
-                       "warm_passes": warm_cfg},
+                       "warm_passes": warm_cfg,
+                       "exchange": (getattr(loop, "exchange_mode", "all_reduce") if getattr(loop, "sync", None) is not None else "none")},
             "whole_step": {"train_gflop_per_tile": w["gflop_tile"],
                            "mfma_frac": round(value / world * w["gflop_tile"] / 1e3 / MFMA_PEAK_TFLOPS, 4)},
         }
+        if args.log_losses:
+            out["losses"] = [float(x.item()) for x in loss_log]
         if args.dtype == "fp8":
             out["config"]["precision"] = ("forward GEMMs of the transformer layers: OCP e4m3 operands, scaled MFMA 16x16x128, fp32 "
                                           "accumulate, per-tensor delayed scaling; backward GEMMs and attention bf16; fp32 masters")

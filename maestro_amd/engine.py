@@ -942,7 +942,11 @@ class MAEEngine(EngineBase):
         return t.reshape(g.Beff // D, g.draw_G, D, -1)[:, g.draw_g].reshape(g.Beff, -1)
 
     def _reference_tie_order(self, g, gbuf, noise: torch.Tensor, struct: torch.Tensor, slot: int):
-        """``tie_order = "torch"``: the reference's two unstable sorts, issued on the host exactly as it issues them.
+        """``tie_order = "torch"``: the reference's two unstable sorts, issued on the host, i.e. the tie order of the
+        CPU reference (what the ``ties_*.npz`` goldens hold).  For parity tests only: in real training the reference issues them
+        on ``x.device``, and torch's accelerator sort breaks ties differently from its CPU sort -- there is no single "reference
+        order" to reproduce; it also puts two host sorts, a host scatter and an extra H2D copy in front of every step's first launch
+        (a ``RuntimeWarning`` says so once when the mode is enabled).
 
         (a) ``maestro/ssl/mae.py:240-242``: ``argsort(noise * (1 - struct))`` -- structurally masked tokens tie at 0, and when more
         than k of them tie, WHICH become masked is torch's sort order.  The masked set chosen by that call is handed to
@@ -951,6 +955,11 @@ class MAEEngine(EngineBase):
         mask tokens (gathered in ascending position order, ``mae.py:259-262``) are scattered in THAT order: in a group of several
         modalities a position can receive another modality's token.  Returned as a per-sample slot map for
         ``mh_unmask_assemble_per_sample``.  The default ("stable") keeps ascending ties and every position's own token."""
+        if not getattr(self, "_tie_warned", False):
+            self._tie_warned = True
+            import warnings
+            warnings.warn("tie_order='torch' reproduces the tie order of the CPU reference (parity tests); it adds host sorts and an "
+                          "H2D copy to every step and is not what the reference does on an accelerator", RuntimeWarning, stacklevel=2)
         B, L, k = g.Beff, g.L, g.k  # noqa: N806
         nz = noise * (1 - struct.float())
         order = torch.argsort(nz, dim=-1)

@@ -173,7 +173,12 @@ def _pick_tile(layout, M, N, K, flags, args) -> int:  # noqa: N803
         # kernel, =1 sends every eligible problem to the 256x256 LDS-DMA tile; MH_DMA_STAGGER=0 picks its lockstep form.
         forced = os.environ.get("MH_GEMM_TILE")
         if forced is not None:
-            return int(forced)
+            t = int(forced)
+            # the ablation builds of the ping-pong tile (MH_TILE_PP_128_DIAG1..5) leave out parts of the kernel: WRONG outputs
+            if TILE_PP_128 < t <= TILE_PP_128 + 5 and os.environ.get("MH_ALLOW_DIAG_TILES") != "1":
+                raise HipExtensionError(f"MH_GEMM_TILE={t} selects a diagnostic build of the ping-pong tile that writes wrong "
+                                        "outputs; set MH_ALLOW_DIAG_TILES=1 to run it on purpose")
+            return t
         dma = os.environ.get("MH_GEMM_DMA", "")[:1]
         if os.environ.get("MH_GEMM_PP", "")[:1] == "0" and dma == "":   # A/B: the round-2 rule (no persistent ping-pong tile)
             return TILE_DMA_256 if _uses_dma(layout, M, N, K, flags) else TILE_REG_128
@@ -250,7 +255,10 @@ def gemm(layout: int, M: int, N: int, K: int, A, lda: int, B, ldb: int, C, ldc: 
         ev[0].record()
     rc = _gemm_tile(tile, *args)
     if rc == -2 and not explicit:      # e.g. MH_GEMM_TILE / MH_GEMM_DMA=1 forced a DMA tile onto a problem with a K tail
-        rc = _gemm_tile(TILE_REG_128 if os.environ.get("MH_GEMM_DMA", "")[:1] == "1" else TILE_AUTO, *args)
+        # the A/B switches that exist to keep a kernel family OUT of the run (MH_GEMM_DMA=1: everything on the DMA tile or the
+        # register tile; MH_GEMM_PP=0: the round-2 dispatch) must not fall back to MH_TILE_AUTO, whose rule may pick that family
+        pinned = os.environ.get("MH_GEMM_DMA", "")[:1] == "1" or os.environ.get("MH_GEMM_PP", "")[:1] == "0"
+        rc = _gemm_tile(TILE_REG_128 if pinned else TILE_AUTO, *args)
     if rc == -2:
         raise HipExtensionError(f"mh_gemm_bf16_tile: problem ({M}, {N}, {K}) does not qualify for tile {tile}")
     _check(rc, "mh_gemm_bf16_tile")

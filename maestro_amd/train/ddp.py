@@ -69,7 +69,13 @@ class GradSync:
     through a bf16 copy; the trailing slot is always exchanged in fp32."""
 
     def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 64 << 20, group=None, always_ready_from: int | None = None,
-                 bucket_dtype: torch.dtype | None = None) -> None:
+                 bucket_dtype: torch.dtype | None = None, mode: str = "all_reduce") -> None:
+        if mode not in ("all_reduce", "rs_ag"):
+            raise ValueError(f"GradSync: mode {mode!r} (all_reduce | rs_ag)")
+        if mode == "rs_ag" and bucket_dtype is not None and bucket_dtype != flat_grad.dtype:
+            raise ValueError("GradSync: mode='rs_ag' exchanges the gradient buffer in place (no bf16 staging)")
+        self.mode = mode
+        self.rank = dist.get_rank(group) if _active(group) else 0
         self.grad, self.group = flat_grad, group
         self.world = dist.get_world_size(group) if _active(group) else 1
         # a one-rank group still exchanges when it exists: `bench.py --rehearse-exchange` drives the RCCL launch plan on one GPU
@@ -90,11 +96,90 @@ class GradSync:
         self.works = []
         self.launched = []
 
+    # ---- mode "rs_ag" (reduce-scatter + all-gather instead of an all-reduce; reference site
+    # maestro/conf/trainer.py:9-14).  Every bucket is reduce-SCATTERED in place: rank r ends up with the SUM of chunk r of the
+    # bucket, [lo + r c, lo + (r + 1) c), c = (hi - lo) / world, and nothing meaningful in the other chunks.  The optimizer then
+    # updates only the owned chunk of every bucket (1 / world of AdamW's 30 bytes per parameter on every rank instead of all of
+    # them) and ``gather_params`` all-gathers the updated fp32 masters in place -- the same bytes on the wire as the all-reduce
+    # (which is this pair inside RCCL), with the optimizer between the two halves.  The short rest of a bucket that 64 x world
+    # elements (the kernels' alignment) do not divide, and the trailing scalar slot, are all-reduced: every rank "owns" those.
+    def _host_staged(self, t: torch.Tensor) -> bool:
+        """gloo rehearsals with device tensors (two ranks sharing one card in the tests): gloo's reduce-scatter / all-gather only
+        take host tensors, so those two collectives go through a host copy there -- blocking, rehearsal only; RCCL never does."""
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def _shard_end(self, lo: int, hi: int) -> int:
+        """``[lo, mid)`` of a payload bucket is reduce-scattered (``mid - lo`` = the largest multiple of 64 x world elements: chunks
+        stay aligned for the kernels), the short rest ``[mid, hi)`` (< 64 x world elements) is all-reduced."""
+        if self.mode != "rs_ag" or not self.exchange:
+            return lo
+        unit = 64 * self.world
+        return lo + (min(hi, self.payload) - lo) // unit * unit
+
+    def owned(self) -> list[tuple[int, int, int, int]]:
+        """After ``finish()``: ``(lo, hi, own_lo, own_hi)`` per exchanged piece of the payload -- this rank holds the reduced
+        gradient on ``[own_lo, own_hi)`` (the whole piece where it was all-reduced) and updates exactly that range."""
+        out = []
+        self._scattered = set()          # the pieces that went through the reduce-scatter (a one-rank rehearsal owns them whole)
+        for lo, hi in sorted(self.launched):
+            hi = min(hi, self.payload)
+            if hi <= lo:
+                continue
+            mid = self._shard_end(lo, hi)
+            if mid > lo:
+                c = (mid - lo) // self.world
+                out.append((lo, mid, lo + self.rank * c, lo + (self.rank + 1) * c))
+                self._scattered.add((lo, mid))
+            if hi > mid:
+                out.append((mid, hi, mid, hi))
+        return out
+
+    def gather_params(self, flat: torch.Tensor) -> list[tuple[int, int]]:
+        """All-gather the updated owned chunks of ``flat`` (same offsets as the gradient buffer) in place; returns the ranges
+        whose non-owned parts were overwritten (the caller refreshes the copies derived from them, e.g. bf16 shadows)."""
+        works, changed = [], []
+        for lo, hi, a, b in self.owned():
+            if (lo, hi) in self._scattered:
+                if self._host_staged(flat):
+                    host = flat[lo:hi].cpu()
+                    dist.all_gather_into_tensor(host, host[a - lo: b - lo].clone(), group=self.group)
+                    flat[lo:hi].copy_(host)
+                else:
+                    works.append(dist.all_gather_into_tensor(flat[lo:hi], flat[a:b], group=self.group, async_op=True))
+                changed.append((lo, hi))
+        for w in works:
+            w.wait()
+        return changed
+
     def _launch(self, lo: int, hi: int) -> None:
         if hi <= lo:
             return
         self.launched.append((lo, hi))
         if not self.exchange:
+            return
+        if self.mode == "rs_ag":
+            if hi > self.payload:                 # the scalar slot (loss mean): a tiny all-reduce of its own
+                self.works.append((dist.all_reduce(self.grad[self.payload:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                                   async_op=True), None))
+                hi = self.payload
+                if hi <= lo:
+                    return
+                self.launched[-1] = (lo, hi)
+                self.launched.append((self.payload, self.grad.numel()))
+            mid = self._shard_end(lo, hi)
+            if mid > lo:
+                c = (mid - lo) // self.world
+                own = self.grad[lo + self.rank * c: lo + (self.rank + 1) * c]
+                if self._host_staged(self.grad):
+                    host = self.grad[lo:mid].cpu()        # (synchronises with the backward kernels that wrote the slice)
+                    part = torch.empty(c, dtype=host.dtype)
+                    dist.reduce_scatter_tensor(part, host, op=dist.ReduceOp.SUM, group=self.group)
+                    own.copy_(part)
+                else:
+                    self.works.append((dist.reduce_scatter_tensor(own, self.grad[lo:mid], op=dist.ReduceOp.SUM, group=self.group,
+                                                                  async_op=True), None))
+            if hi > mid:
+                self.works.append((dist.all_reduce(self.grad[mid:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
             return
         if self.half and hi > self.payload:      # the scalar slot stays fp32: split it off
             self.works.append((dist.all_reduce(self.grad[self.payload:hi], op=dist.ReduceOp.SUM, group=self.group,

@@ -88,6 +88,43 @@ class FusedAdamW:
         if roctx:
             torch.cuda.nvtx.range_pop()
 
+    def step_sharded(self, sync, lr: float | None = None, grad_scale: float = 1.0) -> None:
+        """The update under ``GradSync(mode="rs_ag")`` (after ``sync.finish()``): this rank holds the reduced gradient only on its
+        chunk of every bucket, updates exactly those chunks -- 1 / world of AdamW's 30 bytes per parameter --, then the updated fp32
+        masters are all-gathered in place and the bf16 shadows of the chunks that arrived from other ranks are re-cast locally.
+        The moments of a chunk live on its owner only (``gather_state`` assembles them for a checkpoint).  Parameters after the
+        step are bit-identical on every rank, and equal to the all-reduce plan's up to the summation order inside the collective."""
+        st = self.engine.store
+        if getattr(self.engine, "fp8", None) is not None:
+            raise hip.HipExtensionError("FusedAdamW.step_sharded: not available with dtype='fp8' (the e4m3 shadows of chunks owned "
+                                        "by other ranks would need their scales: use the all-reduce plan)")
+        owned = sync.owned()
+        if getattr(self, "_owned", None) not in (None, owned):
+            raise hip.HipExtensionError("FusedAdamW.step_sharded: the bucket plan changed between steps -- the moments of a chunk "
+                                        "would move to another rank")
+        self._owned = owned
+        self.t += 1
+        lr = self.lr if lr is None else lr
+        lo, hi = self.lo, self.hi
+        for _, _, a, b in owned:
+            a, b = max(a, lo), min(b, hi)
+            if b > a:
+                hip.adamw(st.flat[a:b], st.grad[a:b], self.m[a - lo: b - lo], self.v[a - lo: b - lo], st.half[a:b], b - a, lr,
+                          self.betas[0], self.betas[1], self.eps, self.wd, self.t, grad_scale)
+        for a, b in sync.gather_params(st.flat):
+            a, b = max(a, lo), min(b, hi)
+            if b > a:
+                hip.cast_bf16(st.flat[a:b], st.half[a:b], b - a)
+        st.mark_synced()
+        self.engine._pack_conv_weights()
+
+    def gather_state(self, sync) -> None:
+        """Under ``rs_ag``: assemble the full moments on every rank (all-gather of the owned chunks; for checkpoints)."""
+        if self.lo != 0:
+            raise NotImplementedError("gather_state: sharded moments are only laid out for a trainable span that starts at 0")
+        sync.gather_params(self.m)
+        sync.gather_params(self.v)
+
     def state_dict(self) -> dict:
         return {"m": self.m, "v": self.v, "t": self.t, "lr": self.lr}
 
@@ -139,6 +176,12 @@ class EngineAdamW(torch.optim.AdamW):
         lo, hi = getattr(eng, "trainable_span", (0, st.total))
         span = [p for p in st.params if lo <= st.offset[id(p)] < hi]
         if not all(id(p) in mine for p in span) or getattr(st, "fresh", True):
+            return False
+        # ... and the reverse: a parameter of the group OUTSIDE the span that carries a gradient (stale from an earlier phase with
+        # set_to_none=False, or a module parameter the engine does not own) would be updated and decayed by torch.optim.AdamW.step
+        # but not by the fused launch -- behaviour must not depend on the path taken, so torch's step runs in that case
+        inside = {id(p) for p in span}
+        if any(p.grad is not None for p in g["params"] if id(p) not in inside):
             return False
         # every gradient of the span must BE the flat buffer's slice (the autograd bridge attaches them)
         return all(p.grad is not None and p.grad.data_ptr() == st.g(p).data_ptr() for p in span)

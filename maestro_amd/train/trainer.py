@@ -33,7 +33,13 @@ class PretrainLoop:
     def __init__(self, model, batch_size: int, device, loss: str = "l2_norm", base_lr: float = 3e-5,
                  betas=(0.9, 0.99), weight_decay: float = 0.01, total_steps: int = 1000, world_size: int = 1,
                  final_factor: float = 1e7, bucket_mb: int = 64, exchange: bool | None = None,
-                 accumulate: int = 1, overlap_optimizer: bool = False, bucket_dtype=None, dtype: str | None = None) -> None:
+                 accumulate: int = 1, overlap_optimizer: bool = False, bucket_dtype=None, dtype: str | None = None,
+                 exchange_mode: str | None = None) -> None:
+        """``exchange_mode``: "all_reduce" (default; ``MAESTRO_EXCHANGE`` overrides) -- every bucket is all-reduced, every rank runs
+        the whole AdamW; "rs_ag" -- every bucket is reduce-scattered, a rank updates its 1 / world share of every bucket and the
+        updated fp32 masters are all-gathered (``GradSync`` / ``FusedAdamW.step_sharded``)."""
+        import os
+        self.exchange_mode = exchange_mode or os.environ.get("MAESTRO_EXCHANGE", "all_reduce")
         self.engine = model.engine(batch_size, device, loss=loss, dtype=dtype)
         self.engine.warm_passes = training_warm_passes()     # a training entry point: start-up passes on (engine.py: warm_passes)
         if overlap_optimizer and self.engine.fp8 is not None:
@@ -46,8 +52,10 @@ class PretrainLoop:
         exchange = world_size > 1 if exchange is None else exchange   # True at world_size 1: one-rank rehearsal of the launch plan
         st = self.engine.store
         # the buffer handed to the exchange ends with the scalar slot that carries the step's loss (first bucket)
+        if self.exchange_mode == "rs_ag" and (overlap_optimizer or self.engine.fp8 is not None or bucket_dtype is not None):
+            raise ValueError("exchange_mode='rs_ag' excludes overlap_optimizer, dtype='fp8' and bf16 buckets")
         self.sync = GradSync(st.grad_all, bucket_bytes=bucket_mb << 20, always_ready_from=st.total,
-                             bucket_dtype=bucket_dtype) if exchange else None
+                             bucket_dtype=bucket_dtype, mode=self.exchange_mode) if exchange else None
         self.world = world_size
         if self.sync is not None:
             self.engine.grad_hook = self.sync.ready
@@ -91,7 +99,9 @@ class PretrainLoop:
             eng.store.extra[:1].copy_(loss)     # the loss rides in the first gradient bucket (see ``loss_mean``)
             self.sync.begin()
         eng.backward()
-        if self.sync is not None:   # the last bucket (encoder head + patch embed) is reduced under the first AdamW launch
+        if self.sync is not None and self.sync.mode == "rs_ag":
+            self.opt.step_sharded(self.sync, lr=self.sched.lr(self.it), grad_scale=self.sync.finish())
+        elif self.sync is not None:   # the last bucket (encoder head + patch embed) is reduced under the first AdamW launch
             scale, split, wait_tail = self.sync.finish_split()
             self._optimizer_step(scale, split, wait_tail)
         else:
@@ -133,6 +143,10 @@ class PretrainLoop:
             eng.store.extra[:1].copy_(loss)
             self.sync.begin()
             scale *= self.sync.finish()
+            if self.sync.mode == "rs_ag":
+                self.opt.step_sharded(self.sync, lr=self.sched.lr(self.it), grad_scale=scale)
+                self.it += 1
+                return loss
         self._optimizer_step(scale)
         self.it += 1
         return loss

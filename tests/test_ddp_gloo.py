@@ -251,3 +251,93 @@ def test_loss_slot_bf16_buckets_callback_and_metric_two_ranks():
             assert abs(loss_mean - 15.0) < 1e-6, (tag, loss_mean)   # mean of 10 and 20, read from the exchanged slot
         assert cb_ok, f"rank {rank}: callback did not average the gradients / broadcast the weights"
         assert abs(mean - 3.0) < 1e-9 and count == 2             # (1 + 3 + 2 + 6) / 4 over both ranks
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# mode="rs_ag" (reference site maestro/conf/trainer.py:9-14): reduce-scatter per bucket -> the optimizer on the owned
+# chunk of every bucket -> all-gather of the updated parameters, against the all-reduce plan with the full update on every rank.
+def _adamw_ref(p, g, m, v, t, lr=1e-2, b1=0.9, b2=0.99, eps=1e-8, wd=0.01):
+    """Plain AdamW on tensor slices (test infrastructure: the arithmetic of mh_adamw, torch.optim.AdamW's update)."""
+    p.mul_(1 - lr * wd)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.addcdiv_(m / (1 - b1 ** t), (v / (1 - b2 ** t)).sqrt() + eps, value=-lr)
+
+
+def _rs_ag_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from maestro_amd.train.ddp import GradSync
+    n, slot = 64 * 40, 64                     # payload + the trailing scalar slot (the step's loss)
+    ready = [(64 * 30, n), (64 * 17, 64 * 30), (64 * 10, 64 * 17), (0, 64 * 10)]      # tail first; 13-, 7- and 10-unit pieces
+    results = {}
+    for mode in ("all_reduce", "rs_ag"):
+        params = torch.randn(n, generator=torch.Generator().manual_seed(7))           # same initial parameters on both ranks
+        m, v = torch.zeros(n), torch.zeros(n)
+        buf = torch.zeros(n + slot)
+        sync = GradSync(buf, bucket_bytes=4 * 64 * 12, always_ready_from=n, mode=mode)
+        plans = []
+        for t in (1, 2, 3):
+            buf[:n] = torch.randn(n, generator=torch.Generator().manual_seed(100 * t + rank))    # this rank's gradient
+            buf[n] = float(10 * t + rank)                                                      # this rank's loss
+            sync.begin()
+            for lo, hi in ready:
+                sync.ready(lo, hi)
+            scale = sync.finish()
+            owned = sync.owned()
+            plans.append(owned)
+            for lo, hi, a, b in owned:                      # the optimizer touches the owned range of every bucket only
+                _adamw_ref(params[a:b], buf[a:b] * scale, m[a:b], v[a:b], t)
+            changed = sync.gather_params(params)
+            loss_mean = float(buf[n]) * scale
+        assert plans[0] == plans[1] == plans[2]
+        if mode == "rs_ag":
+            sync.gather_params(m)
+        results[mode] = (params.clone(), m.clone(), plans[0], changed, loss_mean)
+    pa, ma, plan_a, _, la = results["all_reduce"]
+    pr, mr, plan_r, changed, lr_ = results["rs_ag"]
+    gathered = [torch.zeros_like(pr) for _ in range(world)]
+    dist.all_gather(gathered, pr)
+    covered = sorted((lo, hi) for lo, hi, _, _ in plan_r)
+    tiles = covered[0][0] == 0 and covered[-1][1] == n and all(x[1] == y[0] for x, y in zip(covered, covered[1:]))
+    chunks_ok = all((b - a) * world == hi - lo and a == lo + rank * (b - a) and (b - a) % 64 == 0 for lo, hi, a, b in plan_r if (a, b) != (lo, hi))
+    rests_ok = all(hi - lo < 64 * world for lo, hi, a, b in plan_r if (a, b) == (lo, hi))      # only the short rest of a bucket is all-reduced
+    out.put((rank, torch.equal(gathered[0], gathered[1]), float((pr - pa).abs().max()), float((mr - ma).abs().max()),
+             sum(1 for lo, hi, a, b in plan_r if (a, b) != (lo, hi)), len(plan_r), tiles, chunks_ok and rests_ok,
+             all((a, b) == (lo, hi) for lo, hi, a, b in plan_a), la, lr_, changed == [(lo, hi) for lo, hi, a, b in plan_r if (a, b) != (lo, hi)]))
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_all_gather_plan_two_ranks():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_rs_ag_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, dp, dm, sharded, buckets, tiles, chunks_ok, ar_full, la, lr_, changed_ok in res:
+        assert same, f"rank {rank}: parameters differ between the ranks after the all-gather"
+        assert dp < 1e-6 and dm < 1e-6, (rank, dp, dm)      # = the all-reduce plan (two addends: the same sums)
+        assert tiles and chunks_ok and ar_full and changed_ok, rank
+        assert sharded >= 2 and buckets >= 3, (sharded, buckets)
+        assert la == lr_ == (30 + 31) / 2                     # the loss mean rides along in both modes
+
+
+def test_rs_ag_without_a_group_owns_everything():
+    """One process, no group: every bucket is 'owned' whole (the optimizer then runs the classic full update)."""
+    from maestro_amd.train.ddp import GradSync
+    g = torch.zeros(640 + 64)
+    sync = GradSync(g, bucket_bytes=4 * 128, always_ready_from=640, mode="rs_ag")
+    sync.begin()
+    sync.ready(320, 640)
+    sync.ready(0, 320)
+    assert sync.finish() == 1.0
+    assert sync.owned() == [(0, 320, 0, 320), (320, 640, 320, 640)] and sync.gather_params(torch.zeros(640)) == []
+    with pytest.raises(ValueError):
+        GradSync(g, mode="ring")
+    with pytest.raises(ValueError):
+        GradSync(g, mode="rs_ag", bucket_dtype=torch.bfloat16)

@@ -157,6 +157,76 @@ def _plan_worker(rank, world, port, out, bucket_dtype, steps):
     dist.destroy_process_group()
 
 
+def _rs_ag_worker(rank, world, port, out, steps):
+    """``exchange_mode="rs_ag"``: every bucket reduce-scattered, each rank updates its half of every bucket, the fp32 masters
+    all-gathered -- and the SAME run under the all-reduce plan (second model, same seeds) for comparison."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from maestro_amd.train.trainer import PretrainLoop, synthetic_batch
+    dev = torch.device("cuda:0")
+    res = {}
+    for mode in ("all_reduce", "rs_ag"):
+        ds, model = _build_single_groups()
+        loop = PretrainLoop(model, 2, dev, total_steps=50, world_size=world, bucket_mb=1, base_lr=2e-3, exchange_mode=mode)
+        batch = synthetic_batch(ds.dataset, 2, dev, seed=rank)
+        torch.manual_seed(100 + rank)
+        losses = [float(loop.step(batch).item()) for _ in range(steps)]
+        torch.cuda.synchronize()
+        flat = loop.engine.store.flat.cpu()
+        allp = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(allp, flat)
+        half_ok = torch.equal(loop.engine.store.half.float().cpu(), flat.bfloat16().float())     # shadows follow the gathered masters
+        owned = loop.sync.owned()
+        res[mode] = dict(flat=flat, same=all(torch.equal(allp[0], p) for p in allp), losses=losses, half_ok=half_ok,
+                         sharded=sum(hi - lo for lo, hi, a, b in owned if (a, b) != (lo, hi)),
+                         whole=sum(hi - lo for lo, hi, a, b in owned if (a, b) == (lo, hi)), buckets=len(loop.sync.launched),
+                         loss_mean=float(loop.loss_mean.item()))
+        if mode == "rs_ag":      # the moments: owner-only until gathered; afterwards equal on both ranks
+            loop.opt.gather_state(loop.sync)
+            m = loop.opt.m.cpu()
+            allm = [torch.zeros_like(m) for _ in range(world)]
+            dist.all_gather(allm, m)
+            res[mode]["moments_same"] = all(torch.equal(allm[0], x) for x in allm) and float(m.abs().sum()) > 0
+        del loop
+    rel = ((res["rs_ag"]["flat"] - res["all_reduce"]["flat"]).double().norm() / res["all_reduce"]["flat"].double().norm()).item()
+    moved = ((res["all_reduce"]["flat"] - res["rs_ag"]["flat"]).abs().max().item())
+    out.put((rank, {k: {kk: vv for kk, vv in v.items() if kk != "flat"} for k, v in res.items()}, rel, moved))
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_all_gather_plan_equals_the_all_reduce_plan():
+    """SURVEY §8(e) / VERDICT r03 item 8b: ``GradSync(mode="rs_ag")`` + ``FusedAdamW.step_sharded`` on two gloo ranks sharing the
+    card.  Parameters identical on both ranks after 4 steps; equal to the all-reduce plan's (same summands, the collective's
+    order of addition aside); most buckets sharded; bf16 shadows rebuilt from the gathered masters; the loss mean rides along."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 25500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_rs_ag_worker, args=(r, 2, port, out, 4)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = [out.get(timeout=600) for _ in procs]
+    except queue.Empty:
+        for p in procs:
+            p.kill()
+        pytest.fail("rs_ag workers did not finish")
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, r, rel, moved in res:
+        assert r["rs_ag"]["same"] and r["all_reduce"]["same"], (rank, "parameters differ between the ranks")
+        assert r["rs_ag"]["half_ok"] and r["rs_ag"]["moments_same"], rank
+        # all of the payload but the short rest of every bucket (< 64 x world elements each) went through the reduce-scatter
+        assert r["rs_ag"]["sharded"] > 0 and r["rs_ag"]["whole"] < 128 * r["rs_ag"]["buckets"], (rank, r["rs_ag"])
+        assert r["all_reduce"]["sharded"] == 0
+        assert rel < 1e-5, (rank, rel, moved)              # same sums of two addends: in practice bit-equal
+        assert abs(r["rs_ag"]["loss_mean"] - r["all_reduce"]["loss_mean"]) < 1e-5 * abs(r["all_reduce"]["loss_mean"])
+        assert r["rs_ag"]["losses"][-1] < r["rs_ag"]["losses"][0]
+
+
 @pytest.mark.parametrize("bucket_dtype", ["f32", "bf16"])
 def test_full_plan_two_ranks_equal_the_concatenated_batch(bucket_dtype):
     if not torch.cuda.is_available():

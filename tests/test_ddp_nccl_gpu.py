@@ -27,11 +27,12 @@ def _worker(rank, world, port, out):
         filter_targets=[], aerial=conf.InputRasterConfig(image_size=60, patch_size=conf.PatchSizeConfig(mae=20), bands=4,
                                                          norm_bands=[1, 3], norm_fac=255.0)))
     res = {}
-    for mode, bucket_dtype in (("f32", None), ("bf16", torch.bfloat16)):
+    for mode, bucket_dtype in (("f32", None), ("bf16", torch.bfloat16), ("rs_ag", None)):
         torch.manual_seed(1234 + rank)            # DIFFERENT initial weights per rank: the loop must broadcast rank 0's
         model = mae_tiny(datasets=ds, mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=1,
                          model="mae", num_levels=1, depth=2)
-        loop = PretrainLoop(model, 2, dev, total_steps=10, world_size=world, bucket_mb=1, bucket_dtype=bucket_dtype)
+        loop = PretrainLoop(model, 2, dev, total_steps=10, world_size=world, bucket_mb=1, bucket_dtype=bucket_dtype,
+                            exchange_mode="rs_ag" if mode == "rs_ag" else "all_reduce")
         flat0 = loop.engine.store.flat.clone()
         g0 = [torch.zeros_like(flat0) for _ in range(world)]
         dist.all_gather(g0, flat0)
@@ -83,3 +84,42 @@ def test_two_ranks_over_rccl():
             assert buckets >= 2
             for mean_slot, mean_ref in losses:
                 assert abs(mean_slot - mean_ref) <= 1e-6 * abs(mean_ref), (mode, mean_slot, mean_ref)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# RCCL on the ONE-GPU box: the one-rank process group runs the whole data-parallel launch plan -- bucketed
+# collectives issued from the gradient hook between the backward segments, hipGraph capture next to RCCL's watchdog thread, the
+# two-part AdamW under the last bucket -- in a CHILD process started by torch.distributed.run (never an exec of this process,
+# which has initialised the GPU).  With one rank every collective is the identity, so the loss trajectory must equal the plain
+# run's; both exchange modes.
+def _bench_child(extra, launcher):
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MAESTRO_WARM_PASSES="0")
+    cmd = [sys.executable]
+    if launcher:
+        port = 26500 + os.getpid() % 2000 + launcher
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [str(root / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "3", "--batch", "8", "--cpu-seconds", "0",
+            "--no-kernel-timing", "--log-losses", *extra]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (cmd, r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_one_rank_rccl_rehearsal_of_the_exchange_plan():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    plain = _bench_child([], 0)
+    assert plain["config"]["exchange"] == "none" and len(plain["losses"]) == 4
+    for k, mode in enumerate(("all_reduce", "rs_ag"), start=1):
+        reh = _bench_child(["--rehearse-exchange", "--exchange-mode", mode], k)
+        assert reh["config"]["exchange"] == mode and reh["n_gpus"] == 1
+        for a, b in zip(plain["losses"], reh["losses"]):
+            assert a == a and abs(a - b) <= 1e-5 * abs(a), (mode, plain["losses"], reh["losses"])
+        assert reh["losses"][-1] < reh["losses"][0]           # ... and it trains

@@ -758,3 +758,86 @@ def test_instep_tile_tuner_keeps_the_step_intact(golden_dir):
     finally:
         hip._tile_choice.clear()
         hip._tile_choice.update(before)
+
+
+def _tiny_treesat():
+    ds = conf.DatasetsConfig(name_dataset="treesatai_ts", treesatai_ts=conf.TreeSatAITSConfig(
+        filter_targets=[], aerial=conf.InputRasterConfig(image_size=60, patch_size=conf.PatchSizeConfig(mae=20), bands=4,
+                                                         norm_bands=[1, 3], norm_fac=255.0)))
+    torch.manual_seed(0)
+    model = pmae.mae_tiny(datasets=ds, mask=conf.MaskConfig(), interpolate="nearest", fusion_mode="group", inter_depth=1,
+                          model="mae", num_levels=1, depth=2)
+    return ds, model
+
+
+def test_rebuilt_engines_do_not_accumulate_retired_graphs():
+    """an engine that captured hipGraphs and is dropped (``ssl/mae.py`` rebuilds the engine whenever the batch size
+    changes: partial last batch, validation) hands its graphs to a retire list; the NEXT engine's constructor destroys them with
+    the device idle -- the list, and with it the dead engines' private memory pools, must not grow with every rebuild."""
+    import gc
+
+    from maestro_amd import engine as E
+    from maestro_amd.train.trainer import PretrainLoop, synthetic_batch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    ds, model = _tiny_treesat()
+    losses = []
+    for B in (2, 3, 2):  # noqa: N806
+        loop = PretrainLoop(model, B, dev, total_steps=20)
+        batch = synthetic_batch(ds.dataset, B, dev)
+        torch.manual_seed(5)
+        for _ in range(4):
+            losses.append(float(loop.step(batch).item()))
+        assert len(loop.engine._graphs) >= 2, "the segments should have been captured by now"
+        assert not E._RETIRED_GRAPHS, "the previous engine's graphs were not destroyed when this engine was built"
+        model._engine = None
+        del loop
+        gc.collect()
+        assert len(E._RETIRED_GRAPHS) <= 1          # retired, not destroyed, by the collector ...
+    E.drain_retired_graphs()
+    assert not E._RETIRED_GRAPHS and all(x == x for x in losses)
+
+
+def test_a_bare_forward_never_runs_backward_passes():
+    """ADVICE r03: the start-up passes (forward + zero_grad + backward, repeated) are opt-in for the explicit training loops;
+    a forward of a bare engine -- Lightning's sanity-check validation, predict-only runs -- leaves the gradient buffer alone."""
+    from maestro_amd.train.trainer import synthetic_batch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    ds, model = _tiny_treesat()
+    eng = model.engine(2, dev, loss="l2_norm")
+    assert eng.warm_passes == 0
+    eng.store.grad.fill_(7.0)
+    eng.forward(synthetic_batch(ds.dataset, 2, dev))
+    torch.cuda.synchronize()
+    assert bool((eng.store.grad == 7.0).all()), "a plain forward touched the gradient buffer"
+
+
+def test_engine_adamw_leaves_stale_gradients_outside_the_span_to_torch():
+    """a parameter of the optimizer's group that the engine's trainable span does not cover but that carries a
+    gradient (a phase change with ``set_to_none=False``, a parameter the engine does not own) is updated by
+    ``torch.optim.AdamW.step``; the fused launch would skip it, so ``EngineAdamW`` must take torch's path then."""
+    from maestro_amd.train.optim import EngineAdamW
+    from maestro_amd.train.trainer import synthetic_batch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    ds, model = _tiny_treesat()
+    eng = model.engine(2, dev, loss="l2_norm")
+    extra = torch.nn.Parameter(torch.ones(8, device=dev))
+    opt = EngineAdamW(list(eng.store.params) + [extra], lambda: eng, lr=1e-2, weight_decay=0.0)
+    eng.forward(synthetic_batch(ds.dataset, 2, dev))
+    eng.zero_grad()
+    eng.backward()
+    for p in eng.store.params:
+        p.grad = eng.store.g(p)
+    eng.store.fresh = False
+    assert opt._eligible(eng), "the fused launch should serve the plain case"
+    extra.grad = torch.full_like(extra, 0.5)
+    assert not opt._eligible(eng)
+    before = extra.detach().clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(extra.detach(), before), "the stale-gradient parameter was not updated"
