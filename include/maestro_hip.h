@@ -216,6 +216,13 @@ int mh_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int
 /* dqkv bf16 [B,N,3,H,D] from dout bf16 [B,N,H*D]; delta: f32 workspace [B,H,N]. */
 int mh_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                 int B, int N, int H, int D, float scale, void* stream);
+/* The same with an explicit kernel choice (tests, micro-benchmarks): variant 0 = mh_attn_bwd's rule; 1 = two kernels (dQ with the
+ * query on the lane, then dK / dV with the key on the lane: S, P and dS computed in both); 2 = the single-pass kernel (one workgroup
+ * per (batch, head), dQ summed in an fp32 LDS image, S / P / dS computed once; D = 32 and N <= 1024 only, else -2 and nothing is
+ * launched; measured at parity with the two kernels at N = 1024 and slower below: never picked by variant 0).  Same reference arithmetic: the backward of softmax(Q K^T d^-1/2) V (vit_pytorch Attention.forward,
+ * call sites maestro/ssl/mae.py:155-166). */
+int mh_attn_bwd_variant(int variant, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                        void* dqkv, int B, int N, int H, int D, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- patch embed
  * Patch extraction of one modality (maestro/layers/embed.py:57-60 'b d c (h p1) (w p2)' + the loss target of

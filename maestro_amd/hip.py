@@ -365,8 +365,23 @@ def attn_fwd(qkv, out, lse, B, N, H, D, scale):
     call("mh_attn_fwd", qkv, out, lse, _I(B), _I(N), _I(H), _I(D), _F(scale))
 
 
-def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):
-    call("mh_attn_bwd", qkv, out, dout, lse, delta, dqkv, _I(B), _I(N), _I(H), _I(D), _F(scale))
+ATTN_BWD_AUTO, ATTN_BWD_TWO_KERNELS, ATTN_BWD_SINGLE_PASS = 0, 1, 2
+
+
+def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale, variant: int | None = None):
+    """``variant``: None -> ``MH_ATTN_BWD`` (0 = the library's rule, 1 = two kernels, 2 = the single-pass kernel) or the rule;
+    an explicit 2 on a shape whose dQ image does not fit the LDS raises."""
+    if variant is None:
+        variant = int(os.environ.get("MH_ATTN_BWD", "0"))
+        if variant == ATTN_BWD_SINGLE_PASS and not (D == 32 and N <= 1024):
+            variant = ATTN_BWD_TWO_KERNELS
+    if variant == ATTN_BWD_AUTO:
+        return call("mh_attn_bwd", qkv, out, dout, lse, delta, dqkv, _I(B), _I(N), _I(H), _I(D), _F(scale))
+    rc = lib().mh_attn_bwd_variant(_I(variant), ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), _I(B), _I(N), _I(H),
+                                   _I(D), _F(scale), stream())
+    if rc == -2:
+        raise HipExtensionError(f"mh_attn_bwd_variant: N = {N}, D = {D} does not fit the single-pass kernel's LDS image")
+    _check(rc, "mh_attn_bwd_variant")
 
 
 def patchify(img, cols, target, BD, Ctot, S, P, Kpad, norm_bands, n_groups, normalise, rescale_elev):
@@ -687,12 +702,12 @@ def attn_fwd(qkv, out, lse, B, N, H, D, scale):  # noqa: F811
     e1.record()
 
 
-def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):  # noqa: F811
+def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale, variant=None):  # noqa: F811
     if _timer is None:
-        return _attn_bwd_raw(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale)
-    e0, e1 = _timer.record("attn_bwd", 10.0 * B * H * N * N * D, (B, N, H, D))  # algorithmic 5 matmuls (the kernels recompute 2 more)
+        return _attn_bwd_raw(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale, variant)
+    e0, e1 = _timer.record("attn_bwd", 10.0 * B * H * N * N * D, (B, N, H, D))  # algorithmic 5 matmuls (the two-kernel form recomputes 2 more)
     e0.record()
-    _attn_bwd_raw(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale)
+    _attn_bwd_raw(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale, variant)
     e1.record()
 
 

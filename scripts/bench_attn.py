@@ -10,7 +10,7 @@ from maestro_amd import hip  # noqa: E402
 
 dev = torch.device("cuda:0")
 SHAPES = [(32, 1024, 16, 32), (32, 400, 16, 32), (32, 576, 16, 32), (32, 256, 12, 64), (32, 100, 12, 64), (32, 356, 12, 64),
-          (32, 144, 12, 64), (8, 2048, 16, 64)]
+          (32, 144, 12, 64), (32, 448, 12, 64), (8, 2048, 16, 64)]
 
 
 def timed(fn, reps=20):
@@ -32,6 +32,12 @@ for (B, N, H, D) in SHAPES:  # noqa: N806
     lse, delta = torch.empty(B, H, N, device=dev), torch.empty(B, H, N, device=dev)
     dqkv = torch.empty_like(qkv)
     tf = timed(lambda: hip.attn_fwd(qkv, out, lse, B, N, H, D, D ** -0.5))
-    tb = timed(lambda: hip.attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, D ** -0.5))
+    tb = timed(lambda: hip.attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, D ** -0.5, variant=1))
     fl = B * H * N * N * D
-    print(f"B {B:3d} N {N:5d} H {H:2d} D {D:2d}: fwd {tf:7.1f} us {4 * fl / tf / 1e6:7.1f} TF | bwd {tb:7.1f} us {10 * fl / tb / 1e6:7.1f} TF")
+    line = f"B {B:3d} N {N:5d} H {H:2d} D {D:2d}: fwd {tf:7.1f} us {4 * fl / tf / 1e6:7.1f} TF | bwd two kernels {tb:7.1f} us {10 * fl / tb / 1e6:7.1f} TF"
+    if D == 32 and N <= 1024:
+        ref = dqkv.clone()
+        ts = timed(lambda: hip.attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, D ** -0.5, variant=2))
+        rel = ((dqkv.float() - ref.float()).norm() / ref.float().norm()).item()
+        line += f" | single pass {ts:7.1f} us {10 * fl / ts / 1e6:7.1f} TF ({100 * (ts / tb - 1):+5.1f} %, rel diff {rel:.1e})"
+    print(line, flush=True)
