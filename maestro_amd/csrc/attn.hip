@@ -27,6 +27,15 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef ATTN_DIAG
 #define ATTN_DIAG 0
 #endif
+// ATTN_SUM_MFMA = 1: the forward's softmax denominators come out of the matrix cores -- one more 16-row block of "V^T" whose row 0 is all
+// ones, so that O^T's extra row 0 is sum_k P^T[k][q] -- instead of one v_add_f32 per score (the kernel is VALU-bound: 5 -> 4 issue slots per
+// score at D = 32; the 4 extra MFMAs per key tile hold the issue port for 32 cycles).  The sum is then over the bf16-rounded probabilities,
+// the same values the P V product uses.  D = 32 only: same-box A/B -6 % (N = 1024: 155 -> 145 us; N = 400: 36.5 -> 34.5); at D = 64 the
+// kernel is less VALU-bound and the fifth accumulator block is a wash (-4 % ... +2 %), so the fp32 adds stay there.  0
+// (MH_ATTN_FLAGS="-DATTN_SUM_MFMA=0") keeps the fp32 adds everywhere (A/B aid).
+#ifndef ATTN_SUM_MFMA
+#define ATTN_SUM_MFMA 1
+#endif
 // mh_attn_bwd's rule: 0 = always the two kernels.  Round 4 measured the single-pass kernel (variant 2 of mh_attn_bwd_variant) at parity
 // on its best shape (N = 1024, D = 32: 372 vs 358 us) and slower elsewhere (profiles/r04_attn_bwd.txt): explicit variant only.
 #ifndef MH_ATTN_FUSED_BWD_DEFAULT
@@ -163,6 +172,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 
     f32x4 o[2][DT];
     float m[2], lsum[2];
+    constexpr bool SUM_MFMA = ATTN_SUM_MFMA && D == 32;
+    f32x4 ol[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};      // SUM_MFMA: row 0 (lanes 0-15, element 0) = the running denominator of query column lq
+    bf16x8 ones;
+    {
+        const short one = lq == 0 ? (short)0x3F80 : (short)0;     // first operand [row][k]: row 0 = 1.0 (bf16), rows 1-15 = 0
+        const s16x8 r = {one, one, one, one, one, one, one, one};
+        ones = __builtin_bit_cast(bf16x8, r);
+    }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         m[qt] = -INFINITY; lsum[qt] = 0.f;
@@ -226,6 +243,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             // the softmax is VALU-bound (D = 32: ~4 VALU cycles per MFMA cycle): whole-vector expressions so that the
             // scale / shift and the row sum become packed v_pk_fma_f32 / v_pk_add_f32 (two floats per instruction)
             const f32x4 mc4 = {mc, mc, mc, mc};
+            if constexpr (SUM_MFMA) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const f32x4 t = fms4(s[qt][kt], c, mc4);
+                    s[qt][kt] = (f32x4){exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
+                }
+                ol[qt][0] *= alpha;
+            } else {
 #if ATTN_SCALAR_VALU
             float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
 #else
@@ -250,6 +275,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             const float ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
 #endif
             lsum[qt] = lsum[qt] * alpha + ps;
+            }
             // (skipping these multiplies under a wave-uniform `alpha == 1` test -- bit-identical, 9 % fewer VALU instructions on tiles
             //  whose maximum did not move -- measured no gain: profiles/r04_experiments.txt)
 #pragma unroll
@@ -265,6 +291,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][u], o[qt][dt], 0, 0, 0);
             }
+        if constexpr (SUM_MFMA) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) ol[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qt][u], ol[qt], 0, 0, 0);
+        }
     };
     const int nfull = N / 64;
     for (int it = 0; it < nfull; ++it) kv_tile(it, std::false_type{});
@@ -272,9 +304,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + 16 * qt + lq;
-        float lt = lsum[qt];
-        lt += __shfl_xor(lt, 16, 64);
-        lt += __shfl_xor(lt, 32, 64);
+        float lt;
+        if constexpr (SUM_MFMA) {
+            lt = __shfl(ol[qt][0], lq, 64);               // lane lq (group 0) holds row 0 of the query's column
+        } else {
+            lt = lsum[qt];
+            lt += __shfl_xor(lt, 16, 64);
+            lt += __shfl_xor(lt, 32, 64);
+        }
         if (q >= N) continue;
         const float inv = 1.f / lt;
         bf16_t* orow = out + ((size_t)b * N + q) * H * D + (size_t)h * D;
