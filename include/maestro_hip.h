@@ -84,6 +84,19 @@ int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, 
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                       int ldaux, float* colsum, void* stream);
 
+/* mh_gemm_bf16_tile with a caller-lent workspace (round 4).  With it the register-staged kernel splits K when the output has few
+ * 128 x 128 tiles and K is long (tiles <= 128, K >= 2048: e.g. the ViT-L fc2 / fc1-dgrad of a 576-token group: 40 tiles for 256 CUs, 64 K
+ * steps each; splits = min(256 / tiles, K / 512): one workgroup per CU): grid.y = splits, every workgroup stores its fp32 partial tile, the one that arrives last (one arrival counter per tile)
+ * sums the partials in split order -- deterministic -- and runs the epilogue; any epilogue but MH_GEMM_ATOMIC.  The workspace:
+ * >= mh_gemm_splitk_workspace(...) bytes (0 = this problem is not split: the call then behaves like mh_gemm_bf16_tile), 16-byte aligned,
+ * its first 4096 bytes ZERO before the first use (the kernels leave them zero), used by one launch at a time (one workspace per
+ * stream).  workspace = NULL or too small: no split.  Same reference semantics as mh_gemm_bf16 (the nn.Linear calls of vit_pytorch's
+ * blocks, call sites maestro/ssl/mae.py:135-174). */
+long mh_gemm_splitk_workspace(int layout, int M, int N, int K, int flags);
+int mh_gemm_bf16_ws(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                    int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
+                    int ldaux, float* colsum, void* workspace, long workspace_bytes, void* stream);
+
 /* Grouped weight-gradient GEMM: ONE launch over the 256x256 tiles of many independent "TN" problems
  * dW_i[M_i, N_i] (f32) = A_i^T B_i with A_i [K_i, M_i] bf16 (= dY_i), B_i [K_i, N_i] bf16 (= X_i), K_i = tokens.
  * Used to issue all wgrads of a backward segment at once (no split-K, whole-chip tile occupancy).  `table` is a DEVICE

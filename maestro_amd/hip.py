@@ -136,7 +136,38 @@ def set_instep_tuner(t: InStepTuner | None) -> None:
     _instep = t
 
 
+# Split-K workspaces (mh_gemm_bf16_ws): one per stream (a workspace serves one launch at a time; the engine's groups run on parallel
+# streams), allocated on the first eligible launch OUTSIDE a graph capture (the engine's first step runs eagerly), zero-initialised
+# (the arrival counters; the kernels leave them zero).  OPT-IN, MH_GEMM_SPLITK=1: isolated, the few-tile / long-K GEMMs of the ViT-L
+# step get 23-46 % faster (profiles/r04_splitk.txt), but inside the step the groups' streams already share the chip and the A/B of
+# all four BASELINE configurations shows no difference (C4: 21.49 vs 21.52 ms) -- so the default path does not take the workspaces.
+_SPLITK_WS_BYTES = 64 << 20
+_splitk_ws: dict = {}
+
+
+def _splitk_workspace(layout, M, N, K, flags):  # noqa: N803
+    if os.environ.get("MH_GEMM_SPLITK", "0") != "1" or layout == GEMM_TN or (flags & ATOMIC):
+        return None
+    f = lib().mh_gemm_splitk_workspace
+    f.restype = ctypes.c_long
+    need = int(f(_I(layout), _I(M), _I(N), _I(K), _I(flags)))
+    if need <= 0:
+        return None
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    ws = _splitk_ws.get(key)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            return None                # never allocate inside a capture: this launch runs unsplit
+        ws = _splitk_ws[key] = torch.zeros(max(need, _SPLITK_WS_BYTES), dtype=torch.uint8, device="cuda")
+    return ws
+
+
 def _gemm_tile(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum) -> int:  # noqa: N803
+    ws = _splitk_workspace(layout, M, N, K, flags) if tile in (TILE_AUTO, TILE_REG_128) else None
+    if ws is not None:
+        return lib().mh_gemm_bf16_ws(_I(tile), _I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C),
+                                     _I(ldc), _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux),
+                                     ptr(colsum), ptr(ws), _L(ws.numel()), stream())
     return lib().mh_gemm_bf16_tile(_I(tile), _I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C),
                                    _I(ldc), _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux),
                                    ptr(colsum), stream())
