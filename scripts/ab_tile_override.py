@@ -1,6 +1,6 @@
 """In-step A/B of a GEMM tile override without rebuilding the library: pre-populates maestro_amd.hip's per-signature tile table for the
 signatures matched below, then runs bench.py's main with the remaining arguments.
-  python scripts/ab_tile_override.py <rule> [bench args]     rule: none | nn768 (NN, N = 768, K >= 2304, M = 8192 -> DMA-fed 4-wave 128 x 128 tile)"""
+  python scripts/ab_tile_override.py <rule> [bench args]     rule: none | nnpp (plain NN dgrads on the persistent ping-pong tile) | nn768 (NN, N = 768, K >= 2304, M = 8192 -> DMA-fed 4-wave 128 x 128 tile)"""
 import runpy
 import sys
 from pathlib import Path
@@ -21,6 +21,9 @@ def pick(layout, M, N, K, flags, args):  # noqa: N803
     if rule == "nn768b" and layout == 1 and N == 768 and M in (8192, 3200) and not (flags & (hip.MULAUX | hip.ATOMIC)):
         seen[(M, N, K, flags)] = seen.get((M, N, K, flags), 0) + 1
         return hip.TILE_DMA_128x4 if K >= 2304 else hip.TILE_REG_64
+    if rule == "nnpp" and layout == 1 and flags == 0 and K % 64 == 0 and K >= 512 and N % 128 == 0 and -(-M // 128) * (N // 128) >= 256:
+        seen[(M, N, K, flags)] = seen.get((M, N, K, flags), 0) + 1
+        return hip.TILE_PP_128
     return inner(layout, M, N, K, flags, args)
 
 
