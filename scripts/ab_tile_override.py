@@ -24,6 +24,18 @@ def pick(layout, M, N, K, flags, args):  # noqa: N803
     if rule == "nnpp" and layout == 1 and flags == 0 and K % 64 == 0 and K >= 512 and N % 128 == 0 and -(-M // 128) * (N // 128) >= 256:
         seen[(M, N, K, flags)] = seen.get((M, N, K, flags), 0) + 1
         return hip.TILE_PP_128
+    if rule == "m3200_64" and M == 3200 and layout != 2 and not (flags & (hip.COLSUM | hip.ATOMIC)):
+        seen[(M, N, K, flags)] = seen.get((M, N, K, flags), 0) + 1
+        return hip.TILE_REG_64
+    if rule == "n768_64" and N == 768 and M == 8192 and K <= 768 and layout != 2 and not (flags & (hip.COLSUM | hip.ATOMIC)):
+        seen[(M, N, K, flags)] = seen.get((M, N, K, flags), 0) + 1
+        return hip.TILE_REG_64
+    if rule == "dec_pp" and layout == 0 and M == 32768 and not (flags & (hip.GELU | hip.COLSUM | hip.ATOMIC | hip.MULAUX)):
+        seen[(M, N, K, flags)] = seen.get((M, N, K, flags), 0) + 1
+        return hip.TILE_PP_128
+    if rule == "dec_dma" and layout == 0 and M in (32768, 12800) and K % 32 == 0 and not (flags & (hip.COLSUM | hip.ATOMIC)):
+        seen[(M, N, K, flags)] = seen.get((M, N, K, flags), 0) + 1
+        return hip.TILE_DMA_256
     return inner(layout, M, N, K, flags, args)
 
 
