@@ -74,7 +74,9 @@ int mh_gemm_bf16(int layout, int M, int N, int K, const void* A, int lda, const 
 enum { MH_TILE_AUTO = -1, MH_TILE_REG_128 = 0, MH_TILE_DMA_256 = 1, MH_TILE_DMA_256x128 = 2, MH_TILE_DMA_128x256 = 3,
        MH_TILE_DMA_128 = 4, MH_TILE_DMA_128x4 = 5, MH_TILE_DMA_256_LOCKSTEP = 6, MH_TILE_PP_128 = 7,
        /* diagnostic builds of MH_TILE_PP_128 (NT only; outputs are NOT the GEMM's): main loop only / epilogue arithmetic without
-        * its stores / stores without the GELU arithmetic -- the ablation under profiles/ (scripts/bench_pp_ablate.py) */
+        * its stores / stores without the GELU arithmetic -- the ablation under profiles/ (scripts/bench_pp_ablate.py).  They exist
+        * only in a library built with -DMH_DIAG_TILES (MH_BUILD_FLAGS); the shipped library returns -2 for these ids (nothing
+        * launched), so no caller of the C ABI can get a wrong-output kernel by passing a tile id. */
        MH_TILE_PP_128_DIAG1 = 8, MH_TILE_PP_128_DIAG2 = 9, MH_TILE_PP_128_DIAG3 = 10,
        MH_TILE_PP_128_DIAG4 = 11, MH_TILE_PP_128_DIAG5 = 12,  /* full epilogue, other instruction placements */
        /* MH_TILE_REG_128's kernel with 64 x 128 tiles (three workgroups per CU) / 192 x 128 tiles: for outputs whose 128 x 128
@@ -394,6 +396,10 @@ int mh_bce_loss(const float* logits, const float* target, float missing_val, flo
 int mh_colsum(const void* x, int x_is_f32, float* out, int M, int N, int ld, void* stream);
 /* Zero n_spans (offset, length) float ranges of one buffer (spans: device array of 2*n_spans longs; max_len = longest span).
  * Used to clear only the atomically accumulated gradient slots when the weight gradients are stored by the grouped GEMM. */
+/* Read `bytes` bytes at p and discard them (16-byte aligned base; a tail < 16 bytes is not read): brings a weight matrix into the
+ * Infinity Cache ahead of the GEMM that streams it as its B operand (the nn.Linear weights of vit_pytorch's Attention / FeedForward,
+ * call sites maestro/ssl/mae.py:135-174).  No output, no side effect on memory contents. */
+int mh_touch(const void* p, long bytes, void* stream);
 int mh_zero_spans(float* base, const long* spans_device, int n_spans, long max_len, void* stream);
 /* x[0..n) *= *scale with the scalar read on the device; a no-op when it equals 1 (the autograd bridge of the Lightning
  * surface, maestro/train/base.py:242-247: loss.backward() hands over d loss as a device tensor). */

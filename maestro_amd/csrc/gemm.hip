@@ -36,11 +36,8 @@ __global__ __launch_bounds__(NT, MT == 2 ? 3 : 2) void gemm_kernel(GemmParams p)
     // 8 A stripes + 8 B panels (~3 MB at K=768) stay in that XCD's 4 MB L2 instead of a whole B matrix.
     const int id = xcd_remap(blockIdx.x, nwg);
     constexpr int GROUP_M = MT == 2 ? 16 : 8;
-    const int per_group = GROUP_M * p.tiles_n;
-    const int group = id / per_group, in_group = id - group * per_group;
-    const int first_m = group * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
-    const int tile_m = first_m + in_group % gsz, tile_n = in_group / gsz;
+    int tile_m, tile_n;
+    raster_tile<GROUP_M>(p, id, tile_m, tile_n);
     const int m0 = tile_m * TBM, n0 = tile_n * BN;
     const int kbeg = blockIdx.y * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);

@@ -23,6 +23,28 @@ struct GemmParams {
     float* ws = nullptr; int* ws_count = nullptr;
 };
 
+// Output-tile coordinates of raster id `id` (ids already XCD-remapped: every XCD owns a contiguous run).  Ids walk GROUP_M m-tiles
+// before moving to the next n-tile, so the workgroups co-resident under one XCD's L2 cover a GROUP_M x (64 / GROUP_M) block of tiles
+// and sweep the B operand (the weight matrix of a forward / dgrad GEMM) panel by panel.  Group g starts its sweep at n-tile
+// x(g) tiles_n / 8, x(g) = the XCD whose run holds the group (round 5).  Unrotated, whenever the runs line up with the groups
+// (M = 8192: 8 groups, 8 XCDs) all eight XCDs sweep the weight panels in the SAME order at the same time: every panel misses in all
+// eight L2s at once, and inside the step -- where a layer's weights come from HBM, not from the Infinity Cache as in a relaunch loop
+// -- the launch pays that latency at every tile transition: +11 us on a 42 us fc1 launch for 4.7 MB of weights.  Rotated, a panel is
+// fetched from HBM by ONE XCD and found in the Infinity Cache by the others: fc1 72 -> 60 us, qkv 47 -> 37 us with cold operands,
+// C3 step -1 % (profiles/r05_gap_table.md).  A bijection of the tile set for any shape; same fp32 sums per output element.
+template <int GROUP_M>
+__device__ __forceinline__ void raster_tile(const GemmParams& p, int id, int& tile_m, int& tile_n) {
+    const int per_group = GROUP_M * p.tiles_n;
+    const int group = id / per_group, in_group = id - group * per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    tile_m = first_m + in_group % gsz;
+    int n = in_group / gsz;
+    const int groups = (p.tiles_m + GROUP_M - 1) / GROUP_M;
+    n += ((group * 8) / groups) * p.tiles_n / 8;
+    tile_n = n >= p.tiles_n ? n - p.tiles_n : n;
+}
+
 // 8 floats -> 8 OCP fp8 bytes, e4m3 (saturating at +-448: e4m3fn has no infinity, an overflow would become NaN) or e5m2
 // (gradients; saturating at +-57344)
 __device__ __forceinline__ u32x2 pack_fp8x8(f32x4 lo, f32x4 hi, float s, bool e5m2 = false) {

@@ -156,12 +156,8 @@ __global__ __launch_bounds__(T::NT, T::MIN_WG) void gemm_dma_kernel(GemmParams p
     __shared__ __attribute__((aligned(16))) unsigned char smem[T::LDS_BYTES];  // the ONLY LDS object
     const int nwg = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nwg);
-    constexpr int GROUP_M = 4;
-    const int per_group = GROUP_M * p.tiles_n;
-    const int group = id / per_group, in_group = id - group * per_group;
-    const int first_m = group * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
-    const int tile_m = first_m + in_group % gsz, tile_n = in_group / gsz;
+    int tile_m, tile_n;
+    raster_tile<4>(p, id, tile_m, tile_n);
     const int kbeg = blockIdx.y * p.k_per_split;
     gemm_dma_tile<T, A_KMAJOR, B_KMAJOR, 0, STAGGER>(p, tile_m, tile_n, kbeg, min(p.K, kbeg + p.k_per_split), smem);
 }

@@ -66,12 +66,8 @@ __device__ __forceinline__ void gemm_fp8_body(const GemmParams& p, unsigned char
     constexpr int MT = T::MT, NW = T::NW, PA = T::PA, PB = T::PB;
     const int nwg = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nwg);
-    constexpr int GROUP_M = 4;
-    const int per_group = GROUP_M * p.tiles_n;
-    const int group = id / per_group, in_group = id - group * per_group;
-    const int first_m = group * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
-    const int tile_m = first_m + in_group % gsz, tile_n = in_group / gsz;
+    int tile_m, tile_n;
+    raster_tile<4>(p, id, tile_m, tile_n);
     const int m0 = tile_m * T::BM, n0 = tile_n * T::BN;
     const int nk = p.K / BK8;
 

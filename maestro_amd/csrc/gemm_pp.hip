@@ -51,15 +51,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
     if (slot >= cnt) return;   // (uniform: the whole workgroup)
     const int n_my = (cnt - slot + per_x - 1) / per_x;
     const int nk = p.K / BK;
-    constexpr int GROUP_M = 8;
     auto coords = [&](int t, int& m0, int& n0) {
-        const int id = run0 + slot + t * per_x;
-        const int per_group = GROUP_M * p.tiles_n;
-        const int group = id / per_group, in_group = id - group * per_group;
-        const int first_m = group * GROUP_M;
-        const int gsz = min(p.tiles_m - first_m, GROUP_M);
-        m0 = (first_m + in_group % gsz) * BM;
-        n0 = (in_group / gsz) * BN;
+        int tm, tn;
+        raster_tile<8>(p, run0 + slot + t * per_x, tm, tn);
+        m0 = tm * BM;
+        n0 = tn * BN;
     };
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lm = l & 15;
@@ -311,6 +307,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
 template <bool B_KMAJOR>
 void launch_pp(int epi, int grid, const GemmParams& p, hipStream_t s, int diag = 0) {
     dim3 g(grid), b(NT);
+#ifdef MH_DIAG_TILES   // ablation builds only (MH_BUILD_FLAGS=-DMH_DIAG_TILES): the shipped library does not contain these kernels
     if constexpr (!B_KMAJOR) {   // diagnostic builds: NT only, fc1 (GELU) and plain bf16 epilogues
         if (diag == 1 && epi == EPI_GELU) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_GELU, 1>), g, b, 0, s, p); return; }
         if (diag == 2 && epi == EPI_GELU) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_GELU, 2>), g, b, 0, s, p); return; }
@@ -319,6 +316,9 @@ void launch_pp(int epi, int grid, const GemmParams& p, hipStream_t s, int diag =
         if (diag == 5 && epi == EPI_GELU) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_GELU, 5>), g, b, 0, s, p); return; }
         if (diag == 1 && epi == EPI_BF16) { hipLaunchKernelGGL((gemm_pp_kernel<false, EPI_BF16, 1>), g, b, 0, s, p); return; }
     }
+#else
+    (void)diag;
+#endif
     switch (epi) {
         case EPI_BF16: hipLaunchKernelGGL((gemm_pp_kernel<B_KMAJOR, EPI_BF16>), g, b, 0, s, p); break;
         case EPI_GELU: hipLaunchKernelGGL((gemm_pp_kernel<B_KMAJOR, EPI_GELU>), g, b, 0, s, p); break;
@@ -344,6 +344,11 @@ int gemm_pp_dispatch(int layout, int M, int N, int K, const void* A, int lda, co
                      const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out, int ldaux, float* colsum,
                      void* stream, int diag) {
     const int epi = pp_epilogue(flags);
+#ifndef MH_DIAG_TILES
+    if (diag != 0) return -2;   // MH_TILE_PP_128_DIAG1..5 write wrong outputs on purpose: compiled only under -DMH_DIAG_TILES
+#else
+    if (diag != 0 && (layout != 0 || !(epi == EPI_GELU || (epi == EPI_BF16 && diag == 1)))) return -2;   // no such ablation build
+#endif
     if (epi < 0 || layout == 2 || K % BK != 0 || K < EPI_STEPS * BK || N % BN != 0) return -2;
     if (epi == EPI_GELU && !aux_out) return -2;
     const bool b_kmajor = layout == 1;

@@ -205,10 +205,11 @@ def _pick_tile(layout, M, N, K, flags, args) -> int:  # noqa: N803
         forced = os.environ.get("MH_GEMM_TILE")
         if forced is not None:
             t = int(forced)
-            # the ablation builds of the ping-pong tile (MH_TILE_PP_128_DIAG1..5) leave out parts of the kernel: WRONG outputs
+            # the ablation builds of the ping-pong tile (MH_TILE_PP_128_DIAG1..5) leave out parts of the kernel: WRONG outputs.  The
+            # shipped library does not contain them (the C ABI returns -2); a library built with MH_BUILD_FLAGS=-DMH_DIAG_TILES does
             if TILE_PP_128 < t <= TILE_PP_128 + 5 and os.environ.get("MH_ALLOW_DIAG_TILES") != "1":
                 raise HipExtensionError(f"MH_GEMM_TILE={t} selects a diagnostic build of the ping-pong tile that writes wrong "
-                                        "outputs; set MH_ALLOW_DIAG_TILES=1 to run it on purpose")
+                                        "outputs (present only in a -DMH_DIAG_TILES library); set MH_ALLOW_DIAG_TILES=1 to run it on purpose")
             return t
         dma = os.environ.get("MH_GEMM_DMA", "")[:1]
         if os.environ.get("MH_GEMM_PP", "")[:1] == "0" and dma == "":   # A/B: the round-2 rule (no persistent ping-pong tile)
@@ -575,6 +576,11 @@ def ce_loss(logits, target, missing_val, n_valid, acc, dlogits, B, g, P, C, ld=N
 
 def bce_loss(logits, target, missing_val, acc, dlogits, B, C):  # noqa: N803
     call("mh_bce_loss", logits, target, _F(float(missing_val)), acc, dlogits, _I(B), _I(C))
+
+
+def touch(t) -> None:
+    """Read-and-discard sweep of a contiguous tensor (``mh_touch``): warms the Infinity Cache with a weight matrix."""
+    call("mh_touch", t, ctypes.c_long(t.numel() * t.element_size()))
 
 
 def zero_spans(base, spans, n_spans, max_len):

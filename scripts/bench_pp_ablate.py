@@ -7,6 +7,7 @@ C3 step's fc1 / qkv shapes, interleaved rounds in one process:
   valu pinned / valu behind reads   the full kernel with the epilogue's VALU instructions pinned behind every MFMA pair / partly
           behind the fragment reads (sched_group_barrier)
   reg128  the one-tile-per-workgroup kernel (epilogue exposed, LDS-staged) with the same epilogue, and with a plain bf16 one"""
+# NEEDS a library built with MH_BUILD_FLAGS=-DMH_DIAG_TILES (the shipped one declines the DIAG tile ids)
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maestro_amd import hip

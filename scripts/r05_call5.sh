@@ -1,0 +1,11 @@
+#!/bin/bash
+set -o pipefail
+O=gpurun_out/r05; mkdir -p $O
+for v in 0 3 0 3; do
+  MAESTRO_TOUCH_W=$v python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --shapes > $O/touch$v.json 2> $O/touch${v}_shapes.txt || exit 1
+  python - $O/touch$v.json <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); k=d["kernel_times_ms_per_step"]
+print(sys.argv[1], d["value"], d["ms_per_step"], d["step_ms"]["median"], "gemm ms:", round(sum(v for n,v in k.items() if "gemm" in n),3), "attn", round(k["attn_fwd"]+k["attn_bwd"],3))
+PY
+done

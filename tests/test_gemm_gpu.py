@@ -233,6 +233,25 @@ def test_gemm_pp_declines_what_it_does_not_serve():
             hip.gemm(0, 256, N, K, A, 512, A, 512, C, 256, flags, bias=torch.zeros(256, device=dev), tile=hip.TILE_PP_128)
 
 
+def test_shipped_library_has_no_wrong_output_tiles():
+    """MH_TILE_PP_128_DIAG1..5 (ablation builds that skip parts of the kernel) exist only under -DMH_DIAG_TILES: the C ABI of the
+    shipped library declines them (-2, nothing launched, the output untouched) for every layout and epilogue."""
+    import os
+
+    from maestro_amd import hip
+    if "MH_DIAG_TILES" in os.environ.get("MH_BUILD_FLAGS", ""):
+        pytest.skip("an ablation build")
+    dev = _dev()
+    A = torch.ones(256, 512, device=dev, dtype=torch.bfloat16)
+    for layout in (0, 1):
+        for diag in range(1, 6):
+            C = torch.full((256, 512), 7.0, device=dev, dtype=torch.bfloat16)
+            with pytest.raises(hip.HipExtensionError):
+                hip.gemm(layout, 256, 512, 512, A, 512, A.t().contiguous() if layout else A, 512, C, 512, 0, tile=hip.TILE_PP_128 + diag)
+            torch.cuda.synchronize()
+            assert (C == 7.0).all()
+
+
 # ---- MH_TILE_REG_64 / MH_TILE_REG_192: the register-staged kernel with 64 x 128 / 192 x 128 tiles
 @pytest.mark.parametrize("tile_name", ["TILE_REG_64", "TILE_REG_192"])
 @pytest.mark.parametrize("layout", [0, 1])
