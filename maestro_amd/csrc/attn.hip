@@ -140,6 +140,15 @@ __device__ __forceinline__ bf16x8 pack_acc(const f32x4& a, const f32x4& b) {
     return __builtin_bit_cast(bf16x8, r);
 }
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+// operand fragment times a constant, rounded to bf16 once more (the backward kernels fold scale x log2(e) into Q resp. K ONCE per
+// workgroup, so that the S MFMA chain -- started from -lse log2(e) -- ends in the exp2 argument itself: round 5)
+__device__ __forceinline__ bf16x8 scale_frag(bf16x8 f, float c) {
+    const u32x4 u = __builtin_bit_cast(u32x4, f);
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = pack_bf2(__uint_as_float(u[e] << 16) * c, __uint_as_float(u[e] & 0xffff0000u) * c);
+    return __builtin_bit_cast(bf16x8, r);
+}
 
 // =============================================================================================== forward
 template <int D>
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         float part = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[qt][ks] = frag_global(qb, rs, q, N, ks);
+            qf[qt][ks] = scale_frag(frag_global(qb, rs, q, N, ks), scale * LOG2E);   // Q scale log2(e): S' = Q' K^T - lse log2(e) is the exp2 argument
             dof[qt][ks] = frag_global(dob, os, q, N, ks);
             const bf16x8 of = frag_global(ob, os, q, N, ks);
 #pragma unroll
@@ -382,7 +391,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[qt][dt] = (f32x4){0, 0, 0, 0};
-    const float c = scale * LOG2E;
     const int ntile = (N + 63) / 64;
     u32x4 rk[2], rv[2];
     tile_load<D>(kb, rs, 0, N, rk);
@@ -402,13 +410,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         if (q0 >= N) return;
         // dP's accumulators start at -delta[q] (the lane's query: all four rows): the MFMA chain leaves dP - delta, and
         // dS = P (dP - delta) is ONE multiply per score instead of an add and a multiply (round 4; the softmax-gradient VALU work
-        // bounds this kernel: 5.5 -> 4.5 issue slots per score)
+        // bounds this kernel: 5.5 -> 4.5 issue slots per score).  Round 5: S's accumulators start at -lse[q] log2(e) and Q carries
+        // scale log2(e), so the chain leaves the exp2 argument and the scale / shift FMA per score is gone too (4.5 -> 3.5).
         f32x4 s[2][4], dp[2][4];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                s[qt][kt] = (f32x4){0, 0, 0, 0};
+                s[qt][kt] = (f32x4){-lse2[qt], -lse2[qt], -lse2[qt], -lse2[qt]};
 #if ATTN_DIAG & 2
                 dp[qt][kt] = (f32x4){0, 0, 0, 0};
 #else
@@ -439,14 +448,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         bf16x8 dsf[2][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            const f32x4 l4 = {lse2[qt], lse2[qt], lse2[qt], lse2[qt]};
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-#if ATTN_DIAG & 2
                 const f32x4 t = s[qt][kt];
-#else
-                const f32x4 t = fms4(s[qt][kt], c, l4);
-#endif
                 const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
                 s[qt][kt] = mul4(pv, dp[qt][kt]);           // dS / scale = P (dP - delta); the factor is applied to dQ once at the end
             }
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kf[kt][ks] = frag_global(kb, rs, k0 + 16 * kt + lk, N, ks);
+            kf[kt][ks] = scale_frag(frag_global(kb, rs, k0 + 16 * kt + lk, N, ks), scale * LOG2E);   // K scale log2(e): see the dQ kernel
             vf[kt][ks] = frag_global(vb, rs, k0 + 16 * kt + lk, N, ks);
         }
     f32x4 dk[2][DT], dv[2][DT];
@@ -522,7 +526,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { dk[kt][dt] = (f32x4){0, 0, 0, 0}; dv[kt][dt] = (f32x4){0, 0, 0, 0}; }
-    const float c = scale * LOG2E;
     const int ntile = (N + 63) / 64;
     u32x4 rq[2], rd[2];
     tile_load<D>(qb, rs, 0, N, rq);
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         tile_store_tr<D>(do_tr, rd);
         if (threadIdx.x < 64) {
             const int q = q0 + threadIdx.x;
-            s_lse[threadIdx.x] = q < N ? lse[((size_t)b * H + h) * N + q] * LOG2E : INFINITY;
+            s_lse[threadIdx.x] = q < N ? -lse[((size_t)b * H + h) * N + q] * LOG2E : -INFINITY;     // negated: S's initial accumulator
             s_dlt[threadIdx.x] = q < N ? -delta[((size_t)b * H + h) * N + q] : 0.f;   // negated: dP - delta as a packed add
         }
         __syncthreads();
@@ -546,7 +549,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         }
         if (k0 >= N) continue;
         // S[q][key], dP[q][key]: rows = queries 16*qt + 4g + r, col = key
-        // (dP's accumulators start at -delta of their four query rows: see the dQ kernel)
+        // (dP's accumulators start at -delta, S's at -lse log2(e) of their four query rows: see the dQ kernel; a query >= N starts
+        //  at -inf: probability 0)
         f32x4 s[4][2], dp[4][2];
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
@@ -555,8 +559,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #else
             const f32x4 nd4 = *reinterpret_cast<const f32x4*>(s_dlt + 16 * qt + 4 * g);
 #endif
+            const f32x4 nl4 = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) { s[qt][kt] = (f32x4){0, 0, 0, 0}; dp[qt][kt] = nd4; }
+            for (int kt = 0; kt < 2; ++kt) { s[qt][kt] = nl4; dp[qt][kt] = nd4; }
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -573,14 +578,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         bf16x8 pf[2][2], dsf[2][2];  // [kt][u]: k index = query permutation of frag_tr
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-#if ATTN_DIAG & 2
                 const f32x4 t = s[qt][kt];
-#else
-                const f32x4 t = fms4(s[qt][kt], c, l4);                // query >= N: lse2 = +inf -> probability 0
-#endif
                 const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
                 s[qt][kt] = pv;
                 dp[qt][kt] = mul4(pv, dp[qt][kt]);                     // dS / scale = P (dP - delta) (scale applied to dK at the end)
