@@ -294,7 +294,7 @@ def main() -> None:
                             overlap_optimizer=args.overlap_optimizer, dtype=args.dtype, exchange_mode=args.exchange_mode)
     else:
         loop = SupervisedLoop(model, args.batch, dev, phase=args.phase, total_steps=args.steps + args.warmup, world_size=world)
-    warm_cfg = loop.engine.warm_passes     # start-up passes of the first step (engine.py: warm_passes; MAESTRO_WARM_PASSES)
+    warm_engine = loop.engine     # start-up passes of the first step (engine.py: warm_passes; MAESTRO_WARM_PASSES): read AFTER the first step
     batch = synthetic_batch(ds.dataset, args.batch, dev, seed=rank)
     batch.update(synthetic_targets(ds.dataset, args.batch, dev, seed=rank))
     if args.single_stream:
@@ -388,7 +388,7 @@ def main() -> None:
                        "fusion_mode": "group", "inter_depth": 3,
                        "parallelism": f"dp{world}", "params_M": round(loop.engine.store.total / 1e6, 1),
                        "final_loss": round(loss_val, 5), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
-                       "warm_passes": warm_cfg,
+                       "warm_passes": getattr(warm_engine, "warm_passes_run", 0),     # the passes that actually ran (0 under fp8 / overlap)
                        "exchange": (getattr(loop, "exchange_mode", "all_reduce") if getattr(loop, "sync", None) is not None else "none")},
             "whole_step": {"train_gflop_per_tile": w["gflop_tile"],
                            "mfma_frac": round(value / world * w["gflop_tile"] / 1e3 / MFMA_PEAK_TFLOPS, 4)},

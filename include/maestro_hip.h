@@ -86,19 +86,6 @@ int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, 
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                       int ldaux, float* colsum, void* stream);
 
-/* mh_gemm_bf16_tile with a caller-lent workspace (round 4).  With it the register-staged kernel splits K when the output has few
- * 128 x 128 tiles and K is long (tiles <= 128, K >= 2048: e.g. the ViT-L fc2 / fc1-dgrad of a 576-token group: 40 tiles for 256 CUs, 64 K
- * steps each; splits = min(256 / tiles, K / 512): one workgroup per CU): grid.y = splits, every workgroup stores its fp32 partial tile, the one that arrives last (one arrival counter per tile)
- * sums the partials in split order -- deterministic -- and runs the epilogue; any epilogue but MH_GEMM_ATOMIC.  The workspace:
- * >= mh_gemm_splitk_workspace(...) bytes (0 = this problem is not split: the call then behaves like mh_gemm_bf16_tile), 16-byte aligned,
- * its first 4096 bytes ZERO before the first use (the kernels leave them zero), used by one launch at a time (one workspace per
- * stream).  workspace = NULL or too small: no split.  Same reference semantics as mh_gemm_bf16 (the nn.Linear calls of vit_pytorch's
- * blocks, call sites maestro/ssl/mae.py:135-174). */
-long mh_gemm_splitk_workspace(int layout, int M, int N, int K, int flags);
-int mh_gemm_bf16_ws(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
-                    int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
-                    int ldaux, float* colsum, void* workspace, long workspace_bytes, void* stream);
-
 /* Grouped weight-gradient GEMM: ONE launch over the 256x256 tiles of many independent "TN" problems
  * dW_i[M_i, N_i] (f32) = A_i^T B_i with A_i [K_i, M_i] bf16 (= dY_i), B_i [K_i, N_i] bf16 (= X_i), K_i = tokens.
  * Used to issue all wgrads of a backward segment at once (no split-K, whole-chip tile occupancy).  `table` is a DEVICE
@@ -114,30 +101,6 @@ typedef struct MhGroupedGemm {
 } MhGroupedGemm;
 int mh_gemm_grouped_tn(const MhGroupedGemm* table_device, int n_problems, const uint32_t* tile_queues, int queue_len,
                        void* stream);
-
-/* Grouped forward / dgrad GEMM: ONE persistent launch (one 512-thread workgroup per CU) over the tiles of several
- * independent problems of one layout (MH_GEMM_NT or MH_GEMM_NN, argument meaning and epilogue flags as mh_gemm_bf16;
- * no MH_GEMM_ATOMIC), e.g. the same layer-op of every modality group's encoder / decoder (the per-group Transformers of
- * maestro/ssl/mae.py:135-174 run identical ops on different token rows).  K %% 32 == 0, K >= 64, N %% 8 == 0.
- *   problems: DEVICE array; a_bytes / b_bytes = operand extents in bytes ((M-1) lda + K) * 2 etc. -- the buffer descriptors
- *             make rows beyond M / N read as zero; mh_gemm_grouped_check validates a HOST copy of the table.
- *   items:    DEVICE array of n_items work items, two uint32 each: { problem | MH_GTILE_* << 16, (m0 / 64) | (n0 / 64) << 16 }.
- *             Worker w (of n_workers, a multiple of 8, normally the CU count) runs items w', w' + n_workers, ... in order
- *             (w' = (w %% 8) * n_workers / 8 + w / 8: workers on one XCD take neighbouring items); consecutive items of one
- *             shape keep the LDS-DMA pipeline filled across the tile boundary.  The item list must cover every output
- *             element of every problem exactly once (shapes may be mixed freely: the host balances the workers with
- *             half / quarter tiles instead of split-K).  MH_GTILE_128 is not valid for MH_GEMM_COLSUM problems. */
-enum { MH_GTILE_256 = 0, MH_GTILE_128x256 = 1, MH_GTILE_256x128 = 2, MH_GTILE_128 = 3 };   /* rows x cols */
-typedef struct MhGemmProblem {
-    const void* A; const void* B; void* C;
-    const float* bias; const float* res; const void* aux_in; void* aux_out; float* colsum;
-    int M, N, K, lda, ldb, ldc, ldr, ldaux, flags;
-    unsigned a_bytes, b_bytes;
-    int reserved;
-} MhGemmProblem;
-int mh_gemm_grouped_check(int layout, const MhGemmProblem* problems_host, int n_problems);
-int mh_gemm_grouped(int layout, const MhGemmProblem* problems_device, int n_problems, const uint32_t* items_device,
-                    int n_items, int n_workers, void* stream);
 
 /* fp8 GEMM (BASELINE configs[4], "ViT-Base MAE fp8 MFMA path"): C[M, N] = (*descale_a) (*descale_b) A8[M, K] B8[N, K]^T
  * with the epilogues of mh_gemm_bf16 (flags, bias, res, aux_in / aux_out, colsum: same meaning; no MH_GEMM_ATOMIC).  Both
@@ -228,17 +191,12 @@ int mh_colsum_batched(const MhColsumJob* jobs_device, int n_jobs, const uint64_t
  * qkv: bf16 [B, N, 3, H, D] (= to_qkv output, chunk(3) then 'b n (h d) -> b h n d'); out: bf16 [B, N, H*D];
  * lse: f32 [B, H, N] (natural-log sum-exp of the scaled scores, saved for the backward).  D in {32, 64}. */
 int mh_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int D, float scale, void* stream);
-/* dqkv bf16 [B,N,3,H,D] from dout bf16 [B,N,H*D]; delta: f32 workspace [B,H,N]. */
+/* dqkv bf16 [B,N,3,H,D] from dout bf16 [B,N,H*D]; delta: f32 workspace [B,H,N].  Two kernels: dQ with the query on the MFMA lane
+ * (it also computes delta = rowsum(dO * O)), then dK / dV with the key on the lane; S and P are recomputed in both from lse.  The
+ * operand that sits in registers (Q resp. K) is multiplied by scale x log2(e) and rounded to bf16 once more, so the recomputed
+ * probabilities differ from the forward's by one extra bf16 rounding of that operand (within the kernels' 1.5e-2 parity bound). */
 int mh_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                 int B, int N, int H, int D, float scale, void* stream);
-/* The same with an explicit kernel choice (tests, micro-benchmarks): variant 0 = mh_attn_bwd's rule; 1 = two kernels (dQ with the
- * query on the lane, then dK / dV with the key on the lane: S, P and dS computed in both); 2 = the single-pass kernel (one workgroup
- * per (batch, head), dQ summed in an fp32 LDS image, S / P / dS computed once; D = 32 and N <= 1024 only, else -2 and nothing is
- * launched; measured at parity with the two kernels at N = 1024 and slower below: never picked by variant 0).  Same reference arithmetic: the backward of softmax(Q K^T d^-1/2) V (vit_pytorch Attention.forward,
- * call sites maestro/ssl/mae.py:155-166). */
-int mh_attn_bwd_variant(int variant, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
-                        void* dqkv, int B, int N, int H, int D, float scale, void* stream);
-
 /* ---------------------------------------------------------------------------------------------- patch embed
  * Patch extraction of one modality (maestro/layers/embed.py:57-60 'b d c (h p1) (w p2)' + the loss target of
  * maestro/train/model.py:211-229): img f32 [BD, Ctot, S, S] ->

@@ -36,11 +36,6 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef ATTN_SUM_MFMA
 #define ATTN_SUM_MFMA 1
 #endif
-// mh_attn_bwd's rule: 0 = always the two kernels.  Round 4 measured the single-pass kernel (variant 2 of mh_attn_bwd_variant) at parity
-// on its best shape (N = 1024, D = 32: 372 vs 358 us) and slower elsewhere (profiles/r04_attn_bwd.txt): explicit variant only.
-#ifndef MH_ATTN_FUSED_BWD_DEFAULT
-#define MH_ATTN_FUSED_BWD_DEFAULT 0
-#endif
 __device__ __forceinline__ f32x4 fms4(f32x4 a, float c, f32x4 b) {   // a * c - b
 #if ATTN_SCALAR_VALU
     return (f32x4){__builtin_fmaf(a[0], c, -b[0]), __builtin_fmaf(a[1], c, -b[1]), __builtin_fmaf(a[2], c, -b[2]),
@@ -623,276 +618,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 }
 
 
-// =============================================================================================== single-pass backward (round 4)
-// dQ, dK and dV in ONE kernel: S, P = exp2(.) and dS are computed ONCE per (query, key) pair instead of once in each of the two
-// kernels above -- 5 matmuls instead of 7 and HALF the exp / softmax-gradient VALU work, which is what bounds the backward at
-// D = 32 (profiles/r03_isa_budget.txt: vector issue : MFMA cycles = 2.1-2.5).
-//
-// Why this needs another structure: dK / dV want the KEY on the lane (the P / dS accumulators S[q][key] are then the second MFMA
-// operands of dV^T = dO^T P and dK^T = Q^T dS), dQ wants the QUERY on the lane (dQ^T = K^T dS^T), and dQ sums over ALL keys.  So:
-//   * one workgroup per (batch, head) walks every key block -- the dQ sum never leaves the CU: it lives in an fp32 LDS image
-//     dQ^T[d][q] (pitch NP = 4 mod 64 floats: a wave's 16 consecutive queries x 4 row groups 4 NP apart fall on 64 distinct banks)
-//     and is written out once at the end;
-//   * 8 waves (two per SIMD, so that one wave's exp / VALU phase runs under the other's MFMAs); wave w owns keys
-//     256 kb + 32 w .. + 31 of key block kb (K / V fragments and the dK / dV accumulators in registers, as in the dK / dV kernel);
-//   * inner loop over 32-query tiles (Q / dO staged as row + transpose images, 2 x 2 x 32 x 2 D bytes);
-//   * dS is TRANSPOSED through LDS: every wave stores its dS^T[key][q] (32 keys x 32 queries, bf16: four ds_write_b64 per lane) into
-//     its 2 KiB staging image; one tile later -- behind the workgroup barrier the loop has anyway -- an OWNER wave per 16 x 16 tile
-//     of dQ^T[d][q] reads all eight images back (ds_read_b64_tr_b16, exactly as frag_tr<32> reads any [k][n] image) as the second
-//     operands of dQ^T += K^T[d][keys of the block] dS^T (K = 256 keys inside the MFMA chain: no cross-wave sum) and adds the tile
-//     to the image with a plain read-modify-write: per key block every image element has exactly one writer.  (LDS float atomics
-//     instead -- every wave adding its own 32-key partial -- were measured first: ds_add_f32 retires at ~190 cycles per wave
-//     instruction, 2940 us against 440 us with the adds removed at N = 1024: profiles/r04_attn_bwd.txt.)
-//     D = 64: the 8 tiles of a query tile have one owner wave each; D = 32: 4 tiles, waves 0-3 / 4-7 own them on even / odd tiles.
-//     The K^T first operands (lane: row d, eight keys in frag_tr's k order, all 8 key groups of the block) are gathered from
-//     global once per key block.
-// LDS: 4 D NP + 256 D + 16 KiB + 4 NP + 128 bytes <= 160 KiB  ->  D = 32: N <= 1024 (D = 64 would fit N <= 448 but is not
-// instantiated: see attn_bwd_impl).  delta = rowsum(dO * O) is computed in the prologue (and stored, as before).
-template <int D, int NP>
-__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
-                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                             float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H,
-                                                             float scale) {
-    constexpr int KS = D / 32, DT = D / 16, QT = 32, IMG = QT * D * 2, CPR = D / 8;
-    constexpr int TILES = 2 * DT;                                      // 16 x 16 tiles of dQ^T per query tile: 4 (D = 32) or 8
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * D * NP + 4 * IMG + 8 * 2048 + 4 * NP + 4 * QT];
-    float* dq_img = reinterpret_cast<float*>(smem);                    // dQ^T[d][q], pitch NP
-    unsigned char* q_row = smem + 4 * D * NP;
-    unsigned char* q_tr = q_row + IMG;
-    unsigned char* do_row = q_tr + IMG;
-    unsigned char* do_tr = do_row + IMG;
-    unsigned char* stage_all = do_tr + IMG;                            // 8 x [32 keys][32 q] bf16
-    float* s_dlt = reinterpret_cast<float*>(stage_all + 8 * 2048);     // -delta[q], q < NP
-    float* s_lse = s_dlt + NP;                                         // lse[q] log2(e) of the current query tile
-
-    const int wid = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = wid / H, h = wid % H;
-    const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, lk = l & 15;
-    const size_t rs = (size_t)3 * H * D, os = (size_t)H * D;
-    const bf16_t* qb = qkv + (size_t)b * N * rs + (size_t)h * D;
-    const bf16_t* kb = qb + (size_t)H * D;
-    const bf16_t* vb = qb + (size_t)2 * H * D;
-    const bf16_t* dob = dout + (size_t)b * N * os + (size_t)h * D;
-    const bf16_t* ob = out + (size_t)b * N * os + (size_t)h * D;
-    const float* lse_bh = lse + ((size_t)b * H + h) * N;
-    unsigned char* stage = stage_all + w * 2048;
-
-    // ---- prologue: dQ image = 0; delta[q] = sum_d O[q][d] dO[q][d] (CPR consecutive lanes share a row)
-    for (int i = t; i < D * NP; i += 512) dq_img[i] = 0.f;
-    for (int i = t; i < NP; i += 512) s_dlt[i] = 0.f;
-    __syncthreads();
-    for (int base = 0; base < N * CPR; base += 512) {
-        const int i = base + t, row = i / CPR, c = i % CPR;
-        float part = 0.f;
-        if (row < N) {
-            const u32x4 ov = *reinterpret_cast<const u32x4*>(ob + (size_t)row * os + c * 8);
-            const u32x4 dv4 = *reinterpret_cast<const u32x4*>(dob + (size_t)row * os + c * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                part += __uint_as_float(ov[e] << 16) * __uint_as_float(dv4[e] << 16);
-                part += __uint_as_float(ov[e] & 0xffff0000u) * __uint_as_float(dv4[e] & 0xffff0000u);
-            }
-        }
-#pragma unroll
-        for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o, 64);
-        if (row < N && c == 0) {
-            s_dlt[row] = -part;
-            delta[((size_t)b * H + h) * N + row] = part;
-        }
-    }
-
-    const float c = scale * LOG2E;
-    const int ntile = (N + QT - 1) / QT;
-    const int nkb = (N + 255) / 256;
-    // Q / dO tile loader: thread t < 8 D moves one 16-byte chunk (t < 4 D: Q, else dO); threads < 32 also carry the tile's lse
-    const bool ld_on = t < 8 * D;
-    const bool ld_do = t >= 4 * D;
-    const int ld_idx = t % (4 * D), ld_row = ld_idx / CPR, ld_c = ld_idx % CPR;
-    const bf16_t* ld_base = ld_do ? dob : qb;
-    const size_t ld_stride = ld_do ? os : rs;
-    // Both fetches are UNCONDITIONAL loads of a clamped row (rows >= N are zeroed / set to +inf when they are consumed): a load
-    // under a lane predicate sits behind an exec branch, the compiler can then no longer count it, and every wait in the loop
-    // degrades to vmcnt(0) -- which would also wait for the tiles fetched last.
-    auto tile_fetch = [&](int q0) -> u32x4 {
-        const int row = min(q0 + ld_row, N - 1);
-        return *reinterpret_cast<const u32x4*>(ld_base + (size_t)row * ld_stride + ld_c * 8);
-    };
-    auto lse_fetch = [&](int q0) -> float { return lse_bh[min(q0 + (t & (QT - 1)), N - 1)]; };     // (RAW value: no arithmetic here)
-    // owner of dQ^T tile (dt_o, qt_o) of a query tile
-    const int tile_o = TILES == 8 ? w : (w & 3);
-    const int dt_o = tile_o >> 1, qt_o = tile_o & 1;
-
-    for (int kblk = 0; kblk < nkb; ++kblk) {
-        const int k0 = kblk * 256 + 32 * w;
-        const bool active = k0 < N;                                    // wave-uniform
-        bf16x8 kf[2][KS], vf[2][KS];                                   // second operands: col = key
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                kf[kt][ks] = frag_global(kb, rs, k0 + 16 * kt + lk, N, ks);
-                vf[kt][ks] = frag_global(vb, rs, k0 + 16 * kt + lk, N, ks);
-            }
-        // K^T first operands of the owner's dQ product, one per 32-key group j of the block: lane (row d = 16 dt_o + lk, group g)
-        // holds keys 4 g + i (i < 4) and 16 + 4 g + (i - 4) of the group: frag_tr's k order, in which the staged dS^T comes back
-        bf16x8 ktf[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            s16x8 r;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int key = kblk * 256 + 32 * j + (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4));
-                r[i] = key < N ? (short)kb[(size_t)key * rs + 16 * dt_o + lk] : (short)0;
-            }
-            ktf[j] = __builtin_bit_cast(bf16x8, r);
-        }
-        if (!active) {            // no keys left for this wave in the last block: its staging image must read as zeros
-            *reinterpret_cast<u32x4*>(stage + 32 * l) = (u32x4){0, 0, 0, 0};
-            *reinterpret_cast<u32x4*>(stage + 32 * l + 16) = (u32x4){0, 0, 0, 0};
-        }
-        f32x4 dk[2][DT], dv[2][DT];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) { dk[kt][dt] = (f32x4){0, 0, 0, 0}; dv[kt][dt] = (f32x4){0, 0, 0, 0}; }
-        const bool key_tail = k0 + 32 > N;                              // wave-uniform: some of this wave's keys do not exist
-        // dQ^T tile (dt_o, qt_o) of query tile `it` from the eight staged dS^T images, added to the image (one writer per element)
-        auto dq_part = [&](int it) {
-            if (TILES == 4 && ((it & 1) != (w >> 2))) return;
-            f32x4 a = {0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[j], frag_tr<32>(stage_all + j * 2048, qt_o, 0), a, 0, 0, 0);
-            float* col = dq_img + it * QT + 16 * qt_o + lk + (16 * dt_o + 4 * g) * NP;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) col[r * NP] += a[r];
-        };
-        // Q / dO / lse of the next PF query tiles are in flight: with one workgroup per CU nobody else hides a miss, and a block's
-        // Q / dO re-reads come from the Infinity Cache (32 CUs x 256 KiB of operands per XCD do not fit its 4 MiB L2): one tile
-        // ahead (~1000 cycles of work) left ~2000 cycles of every tile exposed.  The loop is unrolled by PF so that every slot is a
-        // fixed set of registers (rotating the slots by moves would read -- i.e. wait for -- the newest loads).
-        constexpr int PF = 3;
-        u32x4 nxt[PF];
-        float lse_nxt[PF];
-#pragma unroll
-        for (int i = 0; i < PF; ++i) { nxt[i] = tile_fetch(i * QT); lse_nxt[i] = lse_fetch(i * QT); }
-        auto tile_body = [&](int it, u32x4& slot, float& lse_slot) {
-            const int q0 = it * QT;
-            __syncthreads();                // tile it - 1 is done everywhere: its images are free, its eight dS^T images complete
-            if (ld_on) {
-                unsigned char* row_img = ld_do ? do_row : q_row;
-                unsigned char* tr_img = ld_do ? do_tr : q_tr;
-                const u32x4 v = q0 + ld_row < N ? slot : (u32x4){0, 0, 0, 0};
-                *reinterpret_cast<u32x4*>(row_img + ld_row * (2 * D) + ((ld_c ^ row_swz<D>(ld_row)) << 4)) = v;
-                *reinterpret_cast<u32x4*>(tr_img + ld_row * (2 * D) + ((((ld_c >> 1) ^ tr_swz<D>(ld_row)) << 5) | ((ld_c & 1) << 4))) = v;
-            }
-            if (t < QT) s_lse[t] = q0 + t < N ? lse_slot * LOG2E : INFINITY;     // query >= N: probability 0
-            slot = tile_fetch(q0 + PF * QT);
-            lse_slot = lse_fetch(q0 + PF * QT);
-            if (it > 0) dq_part(it - 1);
-            __syncthreads();                // images of tile `it` ready; the dS^T images of tile it - 1 have been consumed
-            if (!active) return;
-            // S[q][key], dP[q][key] - delta[q]: rows = queries 16 qt + 4 g + r, col = key 16 kt + lk
-            f32x4 s[2][2], dp[2][2];
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const f32x4 nd4 = *reinterpret_cast<const f32x4*>(s_dlt + q0 + 16 * qt + 4 * g);     // dP starts at -delta
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) { s[qt][kt] = (f32x4){0, 0, 0, 0}; dp[qt][kt] = nd4; }
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    const bf16x8 qfr = frag_row<D>(q_row, 16 * qt, ks);
-                    const bf16x8 dfr = frag_row<D>(do_row, 16 * qt, ks);
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt) {
-                        s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kt][ks], s[qt][kt], 0, 0, 0);
-                        dp[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, vf[kt][ks], dp[qt][kt], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    const f32x4 tt = fms4(s[qt][kt], c, l4);
-                    const f32x4 pv = {exp2_fast(tt[0]), exp2_fast(tt[1]), exp2_fast(tt[2]), exp2_fast(tt[3])};
-                    s[qt][kt] = pv;
-                    dp[qt][kt] = mul4(pv, dp[qt][kt]);                 // dS / scale (applied to dK and dQ at the end)
-                }
-            }
-            if (key_tail) {       // a key >= N has K = V = 0: S = 0, P = exp2(-lse) != 0 -- harmless for dK / dV (those rows are never
-                                  // stored) but dS = -P delta would reach dQ: zero it (one wave of the last key block only)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-                    if (k0 + 16 * kt + lk >= N) {
-#pragma unroll
-                        for (int qt = 0; qt < 2; ++qt) dp[qt][kt] = (f32x4){0, 0, 0, 0};
-                    }
-            }
-            // dS^T into the wave's staging image T[key][q] (4 consecutive queries = 8 bytes per store)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const int key = 16 * kt + lk;
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    const u32x2 pk = {pack_bf2(dp[qt][kt][0], dp[qt][kt][1]), pack_bf2(dp[qt][kt][2], dp[qt][kt][3])};
-                    *reinterpret_cast<u32x2*>(stage + key * 64 + ((qt ^ tr_swz<32>(key)) << 5) + 8 * g) = pk;
-                }
-            }
-            // dV^T[d][key] += dO^T[d][q] P[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key]   (k = the tile's 32 queries)
-            bf16x8 pf[2], dsf[2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                pf[kt] = pack_acc(s[0][kt], s[1][kt]);
-                dsf[kt] = pack_acc(dp[0][kt], dp[1][kt]);
-            }
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const bf16x8 dot = frag_tr<D>(do_tr, dt, 0);
-                const bf16x8 qt_f = frag_tr<D>(q_tr, dt, 0);
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    dv[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[kt], dv[kt][dt], 0, 0, 0);
-                    dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsf[kt], dk[kt][dt], 0, 0, 0);
-                }
-            }
-        };
-        for (int it = 0; it < ntile; it += PF) {
-            tile_body(it, nxt[0], lse_nxt[0]);
-            if (it + 1 < ntile) tile_body(it + 1, nxt[1], lse_nxt[1]);
-            if (it + 2 < ntile) tile_body(it + 2, nxt[2], lse_nxt[2]);
-        }
-        __syncthreads();                    // the last tile's dS^T images are complete
-        dq_part(ntile - 1);
-        if (active) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const int key = k0 + 16 * kt + lk;
-                if (key >= N) continue;
-                bf16_t* krow = dqkv + ((size_t)b * N + key) * rs + (size_t)H * D + (size_t)h * D;
-                bf16_t* vrow = krow + (size_t)H * D;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    u32x2 pk = {pack_bf2(dk[kt][dt][0] * scale, dk[kt][dt][1] * scale), pack_bf2(dk[kt][dt][2] * scale, dk[kt][dt][3] * scale)};
-                    u32x2 pv = {pack_bf2(dv[kt][dt][0], dv[kt][dt][1]), pack_bf2(dv[kt][dt][2], dv[kt][dt][3])};
-                    *reinterpret_cast<u32x2*>(krow + 16 * dt + 4 * g) = pk;
-                    *reinterpret_cast<u32x2*>(vrow + 16 * dt + 4 * g) = pv;
-                }
-            }
-        }
-        __syncthreads();                    // the dS^T images are free (next key block stages / zeroes them); the image sums are final
-    }
-    for (int i = t; i < N * CPR; i += 512) {
-        const int q = i / CPR, ch = i % CPR;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = dq_img[(8 * ch + e) * NP + q] * scale;
-        const u32x4 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-        *reinterpret_cast<u32x4*>(dqkv + ((size_t)b * N + q) * rs + (size_t)h * D + 8 * ch) = pk;
-    }
-}
+// (Round 4's single-pass backward -- one workgroup per (batch, head), dQ summed in an fp32 LDS image -- measured at parity with the two
+// kernels at N = 1024 and slower below (profiles/r04_attn_bwd.txt) and was removed in round 5.)
 
 }  // namespace
 
@@ -907,28 +634,11 @@ extern "C" int mh_attn_fwd(const void* qkv, void* out, float* lse, int B, int N,
     return 0;
 }
 
-// variant: 0 = the library's rule, 1 = the two kernels (dQ, then dK / dV), 2 = the single-pass kernel (-2 when the shape does not fit its LDS)
-static int attn_bwd_impl(int variant, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                         int B, int N, int H, int D, float scale, void* stream) {
+extern "C" int mh_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                           int B, int N, int H, int D, float scale, void* stream) {
     MH_CHECK_ARG(qkv && out && dout && lse && delta && dqkv, "mh_attn_bwd: null pointer");
     MH_CHECK_ARG(B > 0 && N > 0 && H > 0 && (D == 32 || D == 64), "mh_attn_bwd: unsupported shape B=%d N=%d H=%d D=%d", B, N, H, D);
-    MH_CHECK_ARG(variant >= 0 && variant <= 2, "mh_attn_bwd: variant %d", variant);
     hipStream_t s = (hipStream_t)stream;
-    // the single-pass kernel is instantiated for D = 32 only: at D = 64 its register budget (256 per lane at two waves per SIMD:
-    // K / V fragments, 16 dK / dV accumulators, the owner's eight K^T operands, three tiles of prefetch) spills, and it measured
-    // 8-50 % slower than the two kernels on every D = 64 shape of the step (profiles/r04_attn_bwd.txt)
-    const bool fits = D == 32 && N <= 1024;
-    if (variant == 2 && !fits) return -2;
-    const bool fused = variant == 2 || (variant == 0 && fits && MH_ATTN_FUSED_BWD_DEFAULT);
-    if (fused) {
-        dim3 grid(H * B), block(512);
-#define FUSED(DD, NP) hipLaunchKernelGGL((attn_bwd_fused_kernel<DD, NP>), grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)out, \
-                                         (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale)
-        if (N <= 512) FUSED(32, 516); else FUSED(32, 1028);
-#undef FUSED
-        MH_LAUNCH_CHECK();
-        return 0;
-    }
     dim3 grid(ceil_div(N, 128) * H * B), block(256);
     if (D == 64) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, 0, s, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
@@ -939,14 +649,4 @@ static int attn_bwd_impl(int variant, const void* qkv, const void* out, const vo
     }
     MH_LAUNCH_CHECK();
     return 0;
-}
-
-extern "C" int mh_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                           int B, int N, int H, int D, float scale, void* stream) {
-    return attn_bwd_impl(0, qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale, stream);
-}
-
-extern "C" int mh_attn_bwd_variant(int variant, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
-                                   void* dqkv, int B, int N, int H, int D, float scale, void* stream) {
-    return attn_bwd_impl(variant, qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale, stream);
 }

@@ -11,7 +11,6 @@
 // columns of one row: bias/residual/aux are read and C is written with 8/16-byte vectors.
 // Split-K + fp32 atomics (LDS-transposed so each wave instruction adds 256 contiguous bytes) serve the wgrad.
 #include "gemm_reg.hpp"
-#include <algorithm>
 
 namespace {
 
@@ -187,57 +186,6 @@ __global__ __launch_bounds__(NT, MT == 2 ? 3 : 2) void gemm_kernel(GemmParams p)
         }
     }
 
-    // Split-K with an in-kernel fix-up (round 4; p.ws != nullptr, gridDim.y = splits): every workgroup stores its fp32 partial
-    // tile in accumulator order (16-byte stores, 4 KiB per wave instruction) and bumps the tile's arrival counter; the workgroup
-    // whose add came LAST (told by the value the add returned) sums ALL partials in split order -- a fixed order: the result does
-    // not depend on which split arrived last --, resets the counter for the next launch and runs the tile's epilogue; the others
-    // leave.  For outputs with few tiles and a long K (C4: 576 x 1024 x 4096 = 40 tiles for 256 CUs and 64 K steps each).
-    // Hand-off without fences (guide, "Workgroup dispatch, XCD placement & inter-workgroup visibility", first row of the measured
-    // table): every partial byte is stored AND loaded `sc1` (16-byte buffer stores / loads: past the CU's L1, not kept in the
-    // storing XCD's L2), every storing wave waits vmcnt(0), a workgroup barrier, then ONE lane's agent-scope atomic add; the wave
-    // that added last loads after its add has returned, the other waves after the barrier it then joins.  (With agent-scope
-    // fences instead -- __threadfence() is a write-back of the XCD's L2 plus an L1 invalidate, 3.5 us and more per call -- the split
-    // launch took 92 us against 33 us unsplit.)
-    if (p.ws) {
-        volatile int* const s_last = reinterpret_cast<volatile int*>(smem);     // (the operand buffers are free: no extra LDS, the tile
-                                                                               //  heights that sit at the CU's LDS limit keep their occupancy)
-        const int splits = gridDim.y;
-        constexpr int PART = 4 * MT * NT * 4;                          // floats per partial tile
-        constexpr int SC1 = 16;                                        // cache-policy bit of the buffer instructions (gfx940+: sc1)
-        float* const tile_ws = p.ws + (size_t)(tile_m * p.tiles_n + tile_n) * splits * PART;
-        const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void*)tile_ws, (short)0, splits * PART * 4, 0x00020000);
-        const int lane_off = threadIdx.x * 16;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[j][i]), rws, lane_off + (j * MT + i) * (NT * 16),
-                                                       (int)blockIdx.y * (PART * 4), SC1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every storing wave: its partial has left the CU
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int* cnt = p.ws_count + tile_m * p.tiles_n + tile_n;
-            const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *s_last = old == splits - 1;
-            if (old == splits - 1) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every split has arrived
-        }
-        __syncthreads();
-        if (!*s_last) return;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int sidx = 0; sidx < splits; ++sidx) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    acc[j][i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, lane_off + (j * MT + i) * (NT * 16),
-                                                                                                  sidx * (PART * 4), SC1));
-        }
-        __syncthreads();                                               // (s_last and the operand buffers are free for the epilogue's staging)
-    }
-
     // epilogues (gemm_common.hpp): operand buffers are free now (the last loop barrier has been passed); each wave stages
     // through its private 32 x 68 float region (4 x 8704 B = 34 KiB <= the 48 KiB of the smallest tile)
     float* st = reinterpret_cast<float*>(smem) + w * (32 * 68);
@@ -260,54 +208,19 @@ static bool prefer_dma(int layout, int M, int N, int K, int flags) {
     return 10 * tiles >= 9 * 256 * waves;
 }
 
-// Split-K rule of the register-staged kernel (mh_gemm_bf16_ws): outputs whose 128 x 128 tiles fill at most a quarter of the 512
-// workgroup slots and whose K loop is long -- splits so that tiles x splits ~ 512, at least 4 K steps per split.
-static int splitk_splits(int layout, int M, int N, int K, int flags) {
-    // Fitted to a sweep of splits 1-16 on MI355X (profiles/r04_splitk.txt): the split pays when the K loop is long (>= 32 steps of 64) and
-    // the output has at most 128 tiles; the best count keeps tiles x splits within the 256 CUs (ONE workgroup per CU: with a second
-    // round the launch is as slow as unsplit) and leaves every split at least 8 K steps.  40 tiles x 64 steps: 35.0 -> 18.6 us with 6
-    // splits; 72 tiles: 34.4 -> 21.9 (3); 112 tiles: 34.8 -> 26.7 (2); 16-step problems and 150-tile outputs gain nothing at any count.
-    if (layout == 2 || (flags & MH_GEMM_ATOMIC) || K % BK != 0) return 1;
-    const long tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
-    const int ksteps = K / BK;
-    if (tiles > 128 || ksteps < 32) return 1;
-    const int s = (int)std::min<long>(256 / tiles, ksteps / 8);
-    return s >= 2 ? s : 1;
-}
-
-// workspace layout: [MH_SPLITK_COUNTERS arrival counters (ints, zero between launches: a FIXED place, so that problems of different
-// shapes sharing one workspace on one stream never find another problem's partial sums where they expect zeros)] [partial tiles]
-constexpr long MH_SPLITK_COUNTERS = 1024;
-extern "C" long mh_gemm_splitk_workspace(int layout, int M, int N, int K, int flags) {
-    const int s = splitk_splits(layout, M, N, K, flags);
-    if (s <= 1) return 0;
-    const long tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
-    return MH_SPLITK_COUNTERS * 4 + tiles * s * (4 * 4 * NT * 4) * 4;
-}
-
 static int gemm_dispatch(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                          void* C, int ldc, int flags, const float* bias, const float* res, int ldr,
-                         const void* aux_in, void* aux_out, int ldaux, float* colsum, void* ws, long ws_bytes, void* stream);
+                         const void* aux_in, void* aux_out, int ldaux, float* colsum, void* stream);
 
 extern "C" int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                                  void* C, int ldc, int flags, const float* bias, const float* res, int ldr,
                                  const void* aux_in, void* aux_out, int ldaux, float* colsum, void* stream) {
-    return gemm_dispatch(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, nullptr, 0,
-                         stream);
-}
-
-extern "C" int mh_gemm_bf16_ws(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
-                               void* C, int ldc, int flags, const float* bias, const float* res, int ldr,
-                               const void* aux_in, void* aux_out, int ldaux, float* colsum, void* workspace, long workspace_bytes,
-                               void* stream) {
-    MH_CHECK_ARG(!workspace || ((uintptr_t)workspace % 16 == 0 && workspace_bytes >= 0), "mh_gemm_bf16_ws: workspace must be 16-byte aligned");
-    return gemm_dispatch(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, workspace,
-                         workspace_bytes, stream);
+    return gemm_dispatch(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum, stream);
 }
 
 static int gemm_dispatch(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                          void* C, int ldc, int flags, const float* bias, const float* res, int ldr,
-                         const void* aux_in, void* aux_out, int ldaux, float* colsum, void* ws, long ws_bytes, void* stream) {
+                         const void* aux_in, void* aux_out, int ldaux, float* colsum, void* stream) {
     MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_REG_192, "mh_gemm_bf16: tile %d", tile);
     MH_CHECK_ARG(layout >= 0 && layout <= 2, "mh_gemm_bf16: layout %d", layout);
     MH_CHECK_ARG(M > 0 && N > 0 && K > 0, "mh_gemm_bf16: empty problem %d %d %d", M, N, K);
@@ -388,16 +301,6 @@ static int gemm_dispatch(int tile, int layout, int M, int N, int K, const void* 
         const int tiles = p.tiles_m * p.tiles_n;
         const int ksteps = ceil_div(K, BK);
         splits = max(1, min(min(512 / max(tiles, 1), ksteps / 4), 32));
-    } else if (ws && mt == 4 && (tile == MH_TILE_AUTO || tile == MH_TILE_REG_128)) {
-        // split-K with the in-kernel fix-up when the caller lent a workspace that is large enough (and zeroed counters)
-        const int s = splitk_splits(layout, M, N, K, flags);
-        if (s > 1 && mh_gemm_splitk_workspace(layout, M, N, K, flags) <= ws_bytes) {
-            splits = s;
-            const long tiles = (long)p.tiles_m * p.tiles_n;
-            (void)tiles;
-            p.ws_count = reinterpret_cast<int*>(ws);
-            p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + MH_SPLITK_COUNTERS * 4);
-        }
     }
     const int ksteps_per = ceil_div(ceil_div(K, BK), splits);
     p.k_per_split = ksteps_per * BK;

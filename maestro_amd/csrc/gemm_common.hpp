@@ -17,10 +17,6 @@ struct GemmParams {
     // e4m3 copy of the output scaled by *c8_scale, the operand of the next fp8 GEMM, with max |value| folded into *c8_amax
     const float* descale_a = nullptr; const float* descale_b = nullptr;
     uint8_t* c8 = nullptr; const float* c8_scale = nullptr; float* c8_amax = nullptr; int ldc8 = 0;
-    // split-K with an in-kernel fix-up (gemm_kernel, grid.y = splits > 1, any epilogue but MH_GEMM_ATOMIC): fp32 partial tiles in
-    // accumulator order [tile][split][16 MT registers][256 threads] x 16 bytes, and one arrival counter per output tile (zero
-    // between launches: the workgroup that arrives last sums the partials in split order, runs the epilogue and resets it)
-    float* ws = nullptr; int* ws_count = nullptr;
 };
 
 // Output-tile coordinates of raster id `id` (ids already XCD-remapped: every XCD owns a contiguous run).  Ids walk GROUP_M m-tiles

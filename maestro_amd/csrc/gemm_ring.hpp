@@ -1,5 +1,4 @@
-// LDS-DMA ring pieces shared by the large-tile GEMM kernels (gemm_dma.hip: one tile per workgroup; gemm_persist.hip:
-// persistent workgroups walking a work list): tile geometry, the LDS swizzles, per-lane DMA source offsets and the
+// LDS-DMA ring pieces of the large-tile GEMM kernels (gemm_dma.hip): tile geometry, the LDS swizzles, per-lane DMA source offsets and the
 // fragment reads.  See the header comment of gemm_dma.hip for the ring protocol and the two operand images.
 #pragma once
 #include "gemm_common.hpp"

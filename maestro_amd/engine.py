@@ -397,134 +397,6 @@ class Stack:
         return cur, cur16
 
 
-class StackSet:
-    """Several ``Stack``s of one geometry (the per-group encoders, or the per-group decoders: ``maestro/ssl/mae.py:133-166``
-    builds one Transformer per group with identical dims) run LAYER BY LAYER in lockstep: every GEMM op of a layer is ONE
-    persistent grouped launch over all members (``hip.GroupedGemm`` / ``mh_gemm_grouped``) instead of one launch per member,
-    LayerNorm and attention stay per member.  Same kernels' arithmetic, same buffers as ``Stack.forward`` / ``backward``."""
-
-    def __init__(self, eng: "MAEEngine", stacks: list, tag: str) -> None:
-        self.eng, self.stacks, self.tag = eng, list(stacks), tag
-        s0 = self.stacks[0]
-        self.depth = s0.depth
-        self._tables: dict = {}
-
-    @staticmethod
-    def compatible(stacks) -> bool:
-        s0 = stacks[0]
-        return all((st.dim, st.mlp, st.inner, st.depth, st.H, st.Dh) == (s0.dim, s0.mlp, s0.inner, s0.depth, s0.H, s0.Dh)
-                   for st in stacks) and s0.dim % 32 == 0 and s0.mlp % 32 == 0 and s0.inner % 32 == 0 and s0.depth > 0
-
-    def _gemm(self, key, layout, make) -> None:
-        """Launch the grouped GEMM ``key`` (its table is built on first use: all operands are static buffers)."""
-        tab = self._tables.get(key)
-        if tab is None:
-            tab = self._tables[key] = hip.GroupedGemm(layout, [make(st) for st in self.stacks], self.eng.device)
-        tab.launch()
-
-    def forward(self, before_layer=None) -> None:
-        ps = self.eng.store
-        for l in range(self.depth):
-            if before_layer is not None:
-                before_layer(l)
-            for st in self.stacks:
-                attn = st.t.layers[l][0]
-                s = st.saved[l]
-                hip.layernorm_fwd(st.xs[2 * l], st.M, 0, attn.norm.weight, attn.norm.bias, s["h1"], st.M, 0, s["mean1"],
-                                  s["rstd1"], 1, st.M, st.dim)
-            self._gemm(("qkv", l), hip.GEMM_NT, lambda st: dict(
-                A=st.saved[l]["h1"], B=ps.h(st.t.layers[l][0].to_qkv.weight), C=st.saved[l]["qkv"], M=st.M, N=3 * st.inner,
-                K=st.dim, lda=st.dim, ldb=st.dim, ldc=3 * st.inner))
-            for st in self.stacks:
-                s = st.saved[l]
-                hip.attn_fwd(s["qkv"], s["o"], s["lse"], st.Bn, st.N, st.H, st.Dh, st.t.layers[l][0].scale)
-            self._gemm(("proj", l), hip.GEMM_NT, lambda st: dict(
-                A=st.saved[l]["o"], B=ps.h(st.t.layers[l][0].to_out[0].weight), C=st.xs[2 * l + 1], M=st.M, N=st.dim, K=st.inner,
-                lda=st.inner, ldb=st.inner, ldc=st.dim, flags=hip.OUT_F32 | hip.BIAS | hip.RESIDUAL,
-                bias=st.t.layers[l][0].to_out[0].bias, res=st.xs[2 * l], ldr=st.dim))
-            for st in self.stacks:
-                ln2 = st.t.layers[l][1].net[0]
-                s = st.saved[l]
-                hip.layernorm_fwd(st.xs[2 * l + 1], st.M, 0, ln2.weight, ln2.bias, s["h2"], st.M, 0, s["mean2"], s["rstd2"], 1,
-                                  st.M, st.dim)
-            self._gemm(("fc1", l), hip.GEMM_NT, lambda st: dict(
-                A=st.saved[l]["h2"], B=ps.h(st.t.layers[l][1].net[1].weight), C=st.saved[l]["act"], M=st.M, N=st.mlp, K=st.dim,
-                lda=st.dim, ldb=st.dim, ldc=st.mlp, flags=hip.BIAS | hip.GELU | hip.AUX_DGELU | self.eng.aux_flag, bias=st.t.layers[l][1].net[1].bias,
-                aux_out=st.saved[l]["hpre"], ldaux=st.mlp))
-            self._gemm(("fc2", l), hip.GEMM_NT, lambda st: dict(
-                A=st.saved[l]["act"], B=ps.h(st.t.layers[l][1].net[4].weight), C=st.xs[2 * l + 2], M=st.M, N=st.dim, K=st.mlp,
-                lda=st.mlp, ldb=st.mlp, ldc=st.dim, flags=hip.OUT_F32 | hip.BIAS | hip.RESIDUAL,
-                bias=st.t.layers[l][1].net[4].bias, res=st.xs[2 * l + 1], ldr=st.dim))
-
-    def backward(self, dx_outs: list, hi: int | None = None, lo: int = 0, defer: bool = False, ready: bool = True) -> list:
-        """Lockstep counterpart of ``Stack.backward`` for every member: ``dx_outs[i]`` is member i's gradient w.r.t. the
-        output of layer ``hi - 1`` (its bf16 copy already in ``saved[hi-1]["gy16"]``); returns ``[(grad f32, grad bf16)]``."""
-        eng, ps = self.eng, self.eng.store
-        AT = hip.OUT_F32 | hip.ATOMIC  # noqa: N806
-        hi = self.depth if hi is None else hi
-        cur = list(dx_outs)
-        cur16 = [(st.saved[hi - 1]["gy16"] if hi > 0 else st.dx0_16) for st in self.stacks]
-        for l in reversed(range(lo, hi)):
-            mid = [st.dxa if c is not st.dxa else st.dxb for st, c in zip(self.stacks, cur)]
-            nxt = [st.dxa if m is not st.dxa else st.dxb for st, m in zip(self.stacks, mid)]
-            # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-            self._gemm(("dfc2", l, defer), hip.GEMM_NN, lambda st: dict(
-                A=st.saved[l]["gy16"], B=ps.h(st.t.layers[l][1].net[4].weight), C=st.saved[l]["dh"], M=st.M, N=st.mlp, K=st.dim,
-                lda=st.dim, ldb=st.mlp, ldc=st.mlp, flags=hip.MULAUX | hip.COLSUM | eng.aux_flag, aux_in=st.saved[l]["hpre"], ldaux=st.mlp,
-                colsum=st.saved[l]["cs"] if defer else st.cs_ws))
-            if not defer:
-                for st in self.stacks:
-                    s, ff = st.saved[l], st.t.layers[l][1]
-                    hip.colsum(st.cs_ws, ps.g(ff.net[1].bias), st.cs_rows, st.mlp, st.mlp)
-                    hip.gemm(hip.GEMM_TN, st.dim, st.mlp, st.M, s["gy16"], st.dim, s["act"], st.mlp, ps.g(ff.net[4].weight), st.mlp, AT)
-                    hip.gemm(hip.GEMM_TN, st.mlp, st.dim, st.M, s["dh"], st.mlp, s["h2"], st.dim, ps.g(ff.net[1].weight), st.dim, AT)
-            self._gemm(("dfc1", l), hip.GEMM_NN, lambda st: dict(
-                A=st.saved[l]["dh"], B=ps.h(st.t.layers[l][1].net[1].weight), C=st.dh2, M=st.M, N=st.dim, K=st.mlp, lda=st.mlp,
-                ldb=st.dim, ldc=st.dim))
-            for i, st in enumerate(self.stacks):
-                attn, ff = st.t.layers[l]
-                s, ln2, proj = st.saved[l], ff.net[0], attn.to_out[0]
-                x_mid = st.xs[2 * l + 1]
-                if defer:
-                    hip.layernorm_bwd_partial(st.dh2, st.M, 0, x_mid, st.M, 0, ln2.weight, s["mean2"], s["rstd2"], cur[i], mid[i],
-                                              s["gmid16"], s["ws2"], 1, st.M, st.dim)
-                else:
-                    hip.layernorm_bwd(st.dh2, st.M, 0, x_mid, st.M, 0, ln2.weight, s["mean2"], s["rstd2"], cur[i], mid[i],
-                                      s["gmid16"], ps.g(ln2.weight), ps.g(ln2.bias), ps.g(proj.bias), st.ln_ws, 1, st.M, st.dim)
-            # ---- attention: x_mid = x_in + proj(attn(qkv(LN1(x_in))))
-            self._gemm(("dproj", l), hip.GEMM_NN, lambda st: dict(
-                A=st.saved[l]["gmid16"], B=ps.h(st.t.layers[l][0].to_out[0].weight), C=st.do, M=st.M, N=st.inner, K=st.dim,
-                lda=st.dim, ldb=st.inner, ldc=st.inner))
-            for st in self.stacks:
-                attn = st.t.layers[l][0]
-                s = st.saved[l]
-                if not defer:
-                    hip.gemm(hip.GEMM_TN, st.dim, st.inner, st.M, s["gmid16"], st.dim, s["o"], st.inner, ps.g(attn.to_out[0].weight),
-                             st.inner, AT)
-                hip.attn_bwd(s["qkv"], s["o"], st.do, s["lse"], st.delta, s["dqkv"], st.Bn, st.N, st.H, st.Dh, attn.scale)
-                if not defer:
-                    hip.gemm(hip.GEMM_TN, 3 * st.inner, st.dim, st.M, s["dqkv"], 3 * st.inner, s["h1"], st.dim,
-                             ps.g(attn.to_qkv.weight), st.dim, AT)
-            self._gemm(("dqkv", l), hip.GEMM_NN, lambda st: dict(
-                A=st.saved[l]["dqkv"], B=ps.h(st.t.layers[l][0].to_qkv.weight), C=st.dh2, M=st.M, N=st.dim, K=3 * st.inner,
-                lda=3 * st.inner, ldb=st.dim, ldc=st.dim))
-            for i, st in enumerate(self.stacks):
-                attn = st.t.layers[l][0]
-                s, x_in = st.saved[l], st.xs[2 * l]
-                nxt16 = st.saved[l - 1]["gy16"] if l > 0 else st.dx0_16
-                prev_fc2_bias = ps.g(st.t.layers[l - 1][1].net[4].bias) if l > 0 else None
-                if defer:
-                    hip.layernorm_bwd_partial(st.dh2, st.M, 0, x_in, st.M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid[i], nxt[i],
-                                              nxt16, s["ws1"], 1, st.M, st.dim)
-                else:
-                    hip.layernorm_bwd(st.dh2, st.M, 0, x_in, st.M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid[i], nxt[i], nxt16,
-                                      ps.g(attn.norm.weight), ps.g(attn.norm.bias), prev_fc2_bias, st.ln_ws, 1, st.M, st.dim)
-                cur[i], cur16[i] = nxt[i], nxt16
-                if ready:
-                    eng._grads_ready(st.t.layers[l])
-        return list(zip(cur, cur16))
-
-
 # hipGraphs of engines that have been garbage-collected, kept alive until the next SAFE point.  An engine is a reference cycle, so
 # Python finalises a dropped one whenever the cyclic collector happens to run -- possibly between two launches of ANOTHER engine's
 # step, with that engine's graphs in flight.  Destroying CUDAGraph objects at such a moment (hipGraphExecDestroy + release of their
@@ -602,6 +474,7 @@ class EngineBase:
         # ``MAESTRO_WARM_PASSES``, default 6, first engine of the process only); the Lightning surface never does.  bench.py
         # reports the value in its JSON line (``config.warm_passes``).
         self.warm_passes = 0
+        self.warm_passes_run = 0
         # the GELU derivative saved by the fc1 epilogue for the backward: one byte per element (MH_GEMM_AUX_U8, step 0.005 on
         # [-0.129, 1.129]) instead of bf16 -- 1.7 GB less HBM traffic per C3 step; MAESTRO_AUX_U8=0 keeps bf16
         self.aux_flag = hip.AUX_U8 if os.environ.get("MAESTRO_AUX_U8", "1") == "1" else 0
@@ -693,6 +566,7 @@ class EngineBase:
         """``one_pass()``: forward + zero_grad + backward of the current step (same inputs, same draws); see ``warm_passes``."""
         global _PROCESS_WARMED
         n, self.warm_passes = self.warm_passes, 0
+        self.warm_passes_run = 0          # what actually ran (bench.py reports THIS: the passes are skipped under fp8, a captured optimizer, ...)
         if (n <= 0 or _PROCESS_WARMED or getattr(self, "fp8", None) is not None or getattr(self, "_opt", None) is not None
                 or hip.kernel_timer_active() or torch.cuda.is_current_stream_capturing() or not torch.is_grad_enabled()):
             return
@@ -705,6 +579,7 @@ class EngineBase:
         try:
             for _ in range(n):
                 one_pass()
+                self.warm_passes_run += 1
         finally:
             self.grad_hook, self.use_graphs = hook, graphs
 
@@ -903,22 +778,9 @@ class MAEEngine(EngineBase):
             self.joint = Stack(self, m.encoder_inter, self.B, m.joint_N, "joint")
         else:
             self.joint = None
-        # Lockstep sets (opt-in, MAESTRO_GROUPED=1): the GEMM ops of layer l of ALL group encoders (all group decoders, the
-        # joint encoder) as one persistent grouped launch each (mh_gemm_grouped).  Default: one launch per group and op on
-        # parallel streams -- measured on C3 (round 2): 19.4 ms/step with the streams vs 25.3 ms in lockstep: serialising the
-        # groups gives up the overlap of one group's HBM-bound LayerNorm / attention kernels with the other's GEMMs, which is
-        # worth more than the launch-level quantisation the grouped kernel removes (profiles/README.md).
-        self.enc_set = self.dec_set = self.joint_set = None
-        if os.environ.get("MAESTRO_GROUPED", "0") == "1":
-            if self.fp8 is not None:   # the grouped launches are bf16-only: fp8 would silently run (and be reported) as bf16
-                raise hip.HipExtensionError("MAESTRO_GROUPED=1 cannot be combined with dtype='fp8': mh_gemm_grouped has no fp8 form")
-            encs, decs = list(self.enc.values()), list(self.dec.values())
-            if StackSet.compatible(encs):
-                self.enc_set = StackSet(self, encs, "enc")
-            if StackSet.compatible(decs):
-                self.dec_set = StackSet(self, decs, "dec")
-            if self.joint is not None and StackSet.compatible([self.joint]):
-                self.joint_set = StackSet(self, [self.joint], "joint")
+        # (Rounds 2-4 kept an opt-in lockstep mode here -- MAESTRO_GROUPED=1: the GEMM ops of layer l of ALL group stacks as one persistent
+        # grouped launch, ``mh_gemm_grouped`` -- measured at 25.3 ms against 19.4 ms per C3 step and -24 % on C5: serialising the groups
+        # gives up the streams' overlap.  Removed in round 5 with its kernel; the result tables are in profiles/README.md.)
         for g in self.groups:  # per-group LN-backward workspace (final norms; groups run on parallel streams)
             self.gb[g.name]["ln_ws"] = e(max(hip.layernorm_bwd_workspace(g.Beff * g.L, Dd),
                                              hip.layernorm_bwd_workspace(g.Beff * g.N, E)))
@@ -1180,11 +1042,9 @@ class MAEEngine(EngineBase):
         if self._opt is not None:
             self._opt_launch_stages()
 
-        def head(g, part="all"):
+        def head(g):
             def run():
                 gbuf, st = self.gb[g.name], self.enc[g.name]
-                if part == "post":
-                    return head_post(g, gbuf, st)
                 self._opt_wait("embed")
                 # ---- embed: patchify -> conv GEMM -> GroupNorm + encodings into the group sequence
                 for s in g.mods:
@@ -1219,8 +1079,6 @@ class MAEEngine(EngineBase):
                 hip.mask_select(gbuf["noise"], gbuf["struct"], gbuf["vis"], gbuf["msk"], gbuf["inv"], gbuf["mask"], g.Beff,
                                 g.L, g.k)
                 hip.gather_rows(gbuf["xg"], gbuf["vis"], st.x0, g.Beff, g.L, g.N, E, g.N, 0)
-                if part == "pre":
-                    return
                 st.forward(lambda l: self._opt_wait("enc", l))
                 head_post(g, gbuf, st)
             return run
@@ -1235,11 +1093,9 @@ class MAEEngine(EngineBase):
                 hip.layernorm_fwd(st.x_last, g.N, 0, nrm.weight, nrm.bias, gbuf["y_e2d" if self.e2d_identity else "henc"], g.N, 0,
                                   gbuf["mean_e"], gbuf["rstd_e"], g.Beff, g.N, E)
 
-        def tail(g, part="all"):
+        def tail(g):
             def run():
                 gbuf, st = self.gb[g.name], self.dec[g.name]
-                if part == "post":
-                    return tail_post(g, gbuf, st)
                 self._opt_wait("e2d")
                 if self.joint is not None:
                     nrm = self.joint.t.norm
@@ -1259,8 +1115,6 @@ class MAEEngine(EngineBase):
                 else:
                     hip.unmask_assemble(gbuf["y_e2d"], gbuf["inv"], gbuf["tok_table"], gbuf["tok_slot"], gbuf["pos_dec"],
                                         gbuf["dates"], gbuf["date_row"], gbuf["n_dates"], st.x0, g.Beff, g.L, g.N, Dd)
-                if part == "pre":
-                    return
                 st.forward(lambda l: self._opt_wait("dec", l))
                 tail_post(g, gbuf, st)
             return run
@@ -1287,14 +1141,9 @@ class MAEEngine(EngineBase):
                     hip.masked_loss_bands(b["rec"], b["target"], gbuf["mask"], b["cnt"], self.loss_w[s.src], self.loss_acc,
                                           b["drec"], s.Beff, s.n_tok, g.L, s.tok_off, s.K, self.p_loss, s.C_src, s.c0, s.C)
 
-        if self.enc_set is not None:     # embed / mask per group (parallel streams), the encoders in lockstep, final LNs
-            self._run_parallel([head(g, "pre") for g in self.groups])
-            self.enc_set.forward(lambda l: self._opt_wait("enc", l))
-            self._run_parallel([head(g, "post") for g in self.groups])
-        else:
-            self._run_parallel([head(g) for g in self.groups])
+        self._run_parallel([head(g) for g in self.groups])
         if self.joint is not None:
-            (self.joint_set or self.joint).forward(lambda l: self._opt_wait("joint", l))
+            self.joint.forward(lambda l: self._opt_wait("joint", l))
         # a modality with several band-groups: masked ELEMENTS over all of them (their patches differ in size, and under
         # 'shared' / 'monotemp' fusion they live in different sequence sets on different streams) -- the denominator of the
         # modality's loss, needed by every band-group's loss launch: counted here, on the main stream, all masks being final
@@ -1304,12 +1153,7 @@ class MAEEngine(EngineBase):
                     g = m.group_specs[s.group]
                     hip.count_masked_elems(self.gb[g.name]["mask"], g.Beff, g.L, s.tok_off, s.tok_off + s.n_tok,
                                            self.mb[s.name]["cnt"], s.K, s.gi > 0)
-        if self.dec_set is not None:
-            self._run_parallel([tail(g, "pre") for g in self.groups])
-            self.dec_set.forward(lambda l: self._opt_wait("dec", l))
-            self._run_parallel([tail(g, "post") for g in self.groups])
-        else:
-            self._run_parallel([tail(g) for g in self.groups])
+        self._run_parallel([tail(g) for g in self.groups])
         if self._opt is not None and self._opt_events:
             torch.cuda.current_stream().wait_stream(self._opt_stream)   # join (a capture must end with every fork joined)
         if self.fp8 is not None:
@@ -1469,13 +1313,11 @@ class MAEEngine(EngineBase):
         m, E, Dd, ps = self.model, self.E, self.Dd, self.store  # noqa: N806
         AT = hip.OUT_F32 | hip.ATOMIC  # noqa: N806
 
-        def side(g, part="all"):
+        def side(g):
             def run():
                 gbuf, st = self.gb[g.name], self.dec[g.name]
                 nrm = st.t.norm
                 dx, dx16 = st.dxa, st.top16          # gradient w.r.t. the decoder's last residual
-                if part == "post":
-                    return side_post(g, gbuf, st, self._dec_state[g.name][0])
                 for s in g.mods:
                     b = self.mb[s.name]
                     T = s.Beff * s.n_tok  # noqa: N806
@@ -1488,8 +1330,6 @@ class MAEEngine(EngineBase):
                                       None, dx, dx16, ps.g(nrm.weight), ps.g(nrm.bias), st.top_bias_grad(), gbuf["ln_ws"],
                                       s.Beff, s.n_tok, Dd)
                     self._grads_ready(m.embed_to_rec[s.embed])
-                if part == "pre":
-                    return
                 dx0, _ = st.backward(dx, defer=self._plan in ("all", "enc", "ovl"))
                 side_post(g, gbuf, st, dx0)
             return run
@@ -1521,22 +1361,13 @@ class MAEEngine(EngineBase):
                                   gbuf["rstd_j"], None, jt.dxa, jt.top16, ps.g(jn.weight), ps.g(jn.bias),
                                   jt.top_bias_grad(), gbuf["ln_ws"], g.Beff, g.N, E)
 
-        if self.dec_set is not None:
-            self._run_parallel([side(g, "pre") for g in self.groups])
-            res = self.dec_set.backward([st.dxa for st in self.dec_set.stacks], defer=self._plan in ("all", "enc", "ovl"))
-            self._dec_state = {g.name: r for g, r in zip(self.groups, res)}
-            self._run_parallel([side(g, "post") for g in self.groups])
-        else:
-            self._run_parallel([side(g) for g in self.groups])
+        self._run_parallel([side(g) for g in self.groups])
         if self._plan == "enc":
             self._launch_wgrads([(st, 0, st.depth) for st in self.dec.values()])
 
     def _bwd_joint(self) -> None:
         jt = self.joint
-        if self.joint_set is not None:
-            self._djoint = self.joint_set.backward([jt.dxa], defer=self._plan in ("all", "enc", "ovl"))[0][0]
-        else:
-            self._djoint, _ = jt.backward(jt.dxa, defer=self._plan in ("all", "enc", "ovl"))
+        self._djoint, _ = jt.backward(jt.dxa, defer=self._plan in ("all", "enc", "ovl"))
         self._grads_ready(jt.t.norm)
         if self._plan == "enc":
             self._launch_wgrads([(jt, 0, jt.depth)])
@@ -1547,13 +1378,11 @@ class MAEEngine(EngineBase):
         m, E, ps = self.model, self.E, self.store  # noqa: N806
         AT = hip.OUT_F32 | hip.ATOMIC  # noqa: N806
 
-        def side(g, part="all"):
+        def side(g):
             def run():
                 gbuf, st = self.gb[g.name], self.enc[g.name]
                 nrm = st.t.norm
                 s_hi, s_lo = min(hi, st.depth), min(lo, st.depth)
-                if part == "post":
-                    return side_post(g, gbuf, st) if last else None
                 if first:
                     if self.joint is not None:
                         hip.layernorm_bwd(self._djoint, m.joint_N, g.joint_off, st.x_last, g.N, 0, nrm.weight, gbuf["mean_e"],
@@ -1566,8 +1395,6 @@ class MAEEngine(EngineBase):
                                           st.top_bias_grad(), gbuf["ln_ws"], g.Beff, g.N, E)
                     self._grads_ready(nrm)
                     self._enc_state[g.name] = (st.dxa, st.top16)
-                if part == "pre":
-                    return
                 cur, _ = self._enc_state[g.name]
                 self._enc_state[g.name] = st.backward(cur, s_hi, s_lo, defer=self._plan != "fused")
                 if last:
@@ -1591,18 +1418,7 @@ class MAEEngine(EngineBase):
                 hip.unpack_rows_add(b["dw_conv"], ps.g(pe.conv.weight), E, s.K, s.Kpad)
                 hip.colsum(b["dyc"], ps.g(pe.conv.bias), T, E, E)
 
-        if self.enc_set is not None:
-            if first:
-                self._run_parallel([side(g, "pre") for g in self.groups])
-            depth = self.enc_set.depth
-            res = self.enc_set.backward([self._enc_state[g.name][0] for g in self.groups], min(hi, depth), min(lo, depth),
-                                        defer=self._plan != "fused")
-            for g, r in zip(self.groups, res):
-                self._enc_state[g.name] = r
-            if last:
-                self._run_parallel([side(g, "post") for g in self.groups])
-        else:
-            self._run_parallel([side(g) for g in self.groups])
+        self._run_parallel([side(g) for g in self.groups])
         if self._plan == "enc":      # this segment's layers of every group encoder
             self._launch_wgrads([(st, min(lo, st.depth), min(hi, st.depth)) for st in self.enc.values()])
         elif self._plan == "all" and last:

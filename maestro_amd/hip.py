@@ -136,38 +136,7 @@ def set_instep_tuner(t: InStepTuner | None) -> None:
     _instep = t
 
 
-# Split-K workspaces (mh_gemm_bf16_ws): one per stream (a workspace serves one launch at a time; the engine's groups run on parallel
-# streams), allocated on the first eligible launch OUTSIDE a graph capture (the engine's first step runs eagerly), zero-initialised
-# (the arrival counters; the kernels leave them zero).  OPT-IN, MH_GEMM_SPLITK=1: isolated, the few-tile / long-K GEMMs of the ViT-L
-# step get 23-46 % faster (profiles/r04_splitk.txt), but inside the step the groups' streams already share the chip and the A/B of
-# all four BASELINE configurations shows no difference (C4: 21.49 vs 21.52 ms) -- so the default path does not take the workspaces.
-_SPLITK_WS_BYTES = 64 << 20
-_splitk_ws: dict = {}
-
-
-def _splitk_workspace(layout, M, N, K, flags):  # noqa: N803
-    if os.environ.get("MH_GEMM_SPLITK", "0") != "1" or layout == GEMM_TN or (flags & ATOMIC):
-        return None
-    f = lib().mh_gemm_splitk_workspace
-    f.restype = ctypes.c_long
-    need = int(f(_I(layout), _I(M), _I(N), _I(K), _I(flags)))
-    if need <= 0:
-        return None
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-    ws = _splitk_ws.get(key)
-    if ws is None or ws.numel() < need:
-        if torch.cuda.is_current_stream_capturing():
-            return None                # never allocate inside a capture: this launch runs unsplit
-        ws = _splitk_ws[key] = torch.zeros(max(need, _SPLITK_WS_BYTES), dtype=torch.uint8, device="cuda")
-    return ws
-
-
 def _gemm_tile(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum) -> int:  # noqa: N803
-    ws = _splitk_workspace(layout, M, N, K, flags) if tile in (TILE_AUTO, TILE_REG_128) else None
-    if ws is not None:
-        return lib().mh_gemm_bf16_ws(_I(tile), _I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C),
-                                     _I(ldc), _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux),
-                                     ptr(colsum), ptr(ws), _L(ws.numel()), stream())
     return lib().mh_gemm_bf16_tile(_I(tile), _I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C),
                                    _I(ldc), _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux),
                                    ptr(colsum), stream())
@@ -397,23 +366,8 @@ def attn_fwd(qkv, out, lse, B, N, H, D, scale):
     call("mh_attn_fwd", qkv, out, lse, _I(B), _I(N), _I(H), _I(D), _F(scale))
 
 
-ATTN_BWD_AUTO, ATTN_BWD_TWO_KERNELS, ATTN_BWD_SINGLE_PASS = 0, 1, 2
-
-
-def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale, variant: int | None = None):
-    """``variant``: None -> ``MH_ATTN_BWD`` (0 = the library's rule, 1 = two kernels, 2 = the single-pass kernel) or the rule;
-    an explicit 2 on a shape whose dQ image does not fit the LDS raises."""
-    if variant is None:
-        variant = int(os.environ.get("MH_ATTN_BWD", "0"))
-        if variant == ATTN_BWD_SINGLE_PASS and not (D == 32 and N <= 1024):
-            variant = ATTN_BWD_TWO_KERNELS
-    if variant == ATTN_BWD_AUTO:
-        return call("mh_attn_bwd", qkv, out, dout, lse, delta, dqkv, _I(B), _I(N), _I(H), _I(D), _F(scale))
-    rc = lib().mh_attn_bwd_variant(_I(variant), ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), _I(B), _I(N), _I(H),
-                                   _I(D), _F(scale), stream())
-    if rc == -2:
-        raise HipExtensionError(f"mh_attn_bwd_variant: N = {N}, D = {D} does not fit the single-pass kernel's LDS image")
-    _check(rc, "mh_attn_bwd_variant")
+def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):
+    call("mh_attn_bwd", qkv, out, dout, lse, delta, dqkv, _I(B), _I(N), _I(H), _I(D), _F(scale))
 
 
 def patchify(img, cols, target, BD, Ctot, S, P, Kpad, norm_bands, n_groups, normalise, rescale_elev):
@@ -739,12 +693,12 @@ def attn_fwd(qkv, out, lse, B, N, H, D, scale):  # noqa: F811
     e1.record()
 
 
-def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale, variant=None):  # noqa: F811
+def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale):  # noqa: F811
     if _timer is None:
-        return _attn_bwd_raw(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale, variant)
+        return _attn_bwd_raw(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale)
     e0, e1 = _timer.record("attn_bwd", 10.0 * B * H * N * N * D, (B, N, H, D))  # algorithmic 5 matmuls (the two-kernel form recomputes 2 more)
     e0.record()
-    _attn_bwd_raw(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale, variant)
+    _attn_bwd_raw(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale)
     e1.record()
 
 
@@ -831,144 +785,6 @@ class GroupedTN:
         e0.record()
         call("mh_gemm_grouped_tn", self.table, _I(self.n), self.queues, _I(self.queue_len))
         e1.record()
-
-
-# ------------------------------------------------------------------------------------------------ grouped forward / dgrad
-GTILE_256, GTILE_128x256, GTILE_256x128, GTILE_128 = 0, 1, 2, 3
-_GTILE_SHAPE = {GTILE_256: (256, 256), GTILE_128x256: (128, 256), GTILE_256x128: (256, 128), GTILE_128: (128, 128)}
-# relative time of one tile per unit of K against the full 256 x 256 tile (smaller wave tiles read more LDS bytes per MFMA
-# and pay the same per-tile epilogue / turnover): used by the host scheduler only, never for correctness
-GTILE_COST = {GTILE_256: 1.0, GTILE_128x256: 0.56, GTILE_256x128: 0.56, GTILE_128: 0.32}
-
-
-class _MhGemmProblem(ctypes.Structure):
-    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
-                ("res", ctypes.c_void_p), ("aux_in", ctypes.c_void_p), ("aux_out", ctypes.c_void_p), ("colsum", ctypes.c_void_p),
-                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("lda", ctypes.c_int), ("ldb", ctypes.c_int),
-                ("ldc", ctypes.c_int), ("ldr", ctypes.c_int), ("ldaux", ctypes.c_int), ("flags", ctypes.c_int),
-                ("a_bytes", ctypes.c_uint), ("b_bytes", ctypes.c_uint), ("reserved", ctypes.c_int)]
-
-
-def n_compute_units(device=None) -> int:
-    return torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
-
-
-def plan_grouped_tiles(shapes, n_workers: int, split=None):
-    """Host scheduler of ``mh_gemm_grouped``: ``shapes`` = [(M, N, K, allow_quarter)] -> list of work items
-    ``(problem, tile type, m0, n0)`` in execution order, and the predicted makespan in units of (full tile x K).
-
-    Every problem is cut into 256 x 256 tiles (a remainder of <= 128 rows / columns becomes a strip of half tiles).  Worker
-    w runs items w, w + G, w + 2G, ... of the list, which is sorted by decreasing cost, so all workers share the rounds of
-    full tiles evenly; the full tiles of the last, partial round are cut into halves or quarters (``split`` = 1, 2, 4;
-    default: whichever gives the shortest makespan) instead of leaving most CUs idle for a whole tile time."""
-    full, edge = [], []
-    for pi, (M, N, K, quarter_ok) in enumerate(shapes):  # noqa: N806
-        nfm, rm = divmod(M, 256)
-        nfn, rn = divmod(N, 256)
-        m_strip = 0 < rm <= 128          # a strip of 128-row tiles; a remainder above 128 rows is a (partly empty) full tile
-        n_strip = 0 < rn <= 128
-        tm = nfm + (1 if rm > 128 else 0)
-        tn = nfn + (1 if rn > 128 else 0)
-        # GROUP_M-style order: 4 m-tiles deep, so that the 32 tiles an XCD runs at a time share A stripes and B panels
-        order = [(mi, ni) for g0 in range(0, tm, 4) for ni in range(tn) for mi in range(g0, min(g0 + 4, tm))]
-        full += [(K * GTILE_COST[GTILE_256], pi, GTILE_256, 256 * mi, 256 * ni) for mi, ni in order]
-        if m_strip:
-            edge += [(K * GTILE_COST[GTILE_128x256], pi, GTILE_128x256, 256 * tm, 256 * ni) for ni in range(tn)]
-        if n_strip:
-            edge += [(K * GTILE_COST[GTILE_256x128], pi, GTILE_256x128, 256 * mi, 256 * tn) for mi in range(tm)]
-        if m_strip and n_strip:
-            edge.append((K * GTILE_COST[GTILE_128 if quarter_ok else GTILE_128x256], pi,
-                         GTILE_128 if quarter_ok else GTILE_128x256, 256 * tm, 256 * tn))
-    full.sort(key=lambda t: -t[0])   # stable: raster order survives inside one K
-
-    def cut(tile, f):
-        """A full tile in f pieces; a half tile (edge strip) in f / 2 pieces."""
-        cost, pi, tt, m0, n0 = tile
-        K = cost / GTILE_COST[tt]  # noqa: N806
-        if f == 4 and not shapes[pi][3]:
-            f = 2
-        if tt == GTILE_256 and f == 2:
-            return [(K * GTILE_COST[GTILE_128x256], pi, GTILE_128x256, m0 + dm, n0) for dm in (0, 128)]
-        if tt == GTILE_256 and f == 4:
-            return [(K * GTILE_COST[GTILE_128], pi, GTILE_128, m0 + dm, n0 + dn) for dm in (0, 128) for dn in (0, 128)]
-        if tt == GTILE_128x256 and f == 4:
-            return [(K * GTILE_COST[GTILE_128], pi, GTILE_128, m0, n0 + dn) for dn in (0, 128)]
-        if tt == GTILE_256x128 and f == 4:
-            return [(K * GTILE_COST[GTILE_128], pi, GTILE_128, m0 + dm, n0) for dm in (0, 128)]
-        return [tile]
-
-    def build(f):
-        left = len(full) % n_workers
-        head, tail = (full[: len(full) - left], full[len(full) - left:]) if left else (full, [])
-        items = head + sorted([c for t in tail + edge for c in cut(t, f)], key=lambda t: -t[0])
-        load = [0.0] * n_workers
-        for k, it in enumerate(items):
-            load[k % n_workers] += it[0]
-        return max(load), items
-
-    best = min((build(f) for f in ((split,) if split else (1, 2, 4))), key=lambda r: r[0])
-    unit = max(s[2] for s in shapes)
-    return [(pi, tt, m0, n0) for _, pi, tt, m0, n0 in best[1]], best[0] / unit
-
-
-class GroupedGemm:
-    """Descriptor table + work list (built once: all buffers are static) for ``mh_gemm_grouped``: several independent NT
-    (``layout`` 0) or NN (1) problems with their own epilogues in ONE persistent launch.  ``problems``: dicts with the keyword
-    arguments of :func:`gemm` (A, B, C, M, N, K, lda, ldb, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum)."""
-
-    @staticmethod
-    def eligible(layout, prob) -> bool:
-        return (layout in (GEMM_NT, GEMM_NN) and prob["K"] % 32 == 0 and prob["K"] >= 64 and prob["N"] % 8 == 0
-                and not (prob.get("flags", 0) & ATOMIC))
-
-    def __init__(self, layout: int, problems, device, n_workers: int | None = None, split=None) -> None:
-        if not problems:
-            raise HipExtensionError("GroupedGemm: no problems")
-        self.layout, self.n = layout, len(problems)
-        self.n_workers = n_workers or max(8, n_compute_units(device) // 8 * 8)
-        arr = (_MhGemmProblem * len(problems))()
-        self.keep, shapes = [], []
-        for i, pr in enumerate(problems):
-            A, B, C = pr["A"], pr["B"], pr["C"]  # noqa: N806
-            M, N, K, lda, ldb, ldc = pr["M"], pr["N"], pr["K"], pr["lda"], pr["ldb"], pr["ldc"]  # noqa: N806
-            flags = pr.get("flags", 0)
-            want_c = torch.float32 if flags & OUT_F32 else torch.bfloat16
-            if A.dtype != torch.bfloat16 or B.dtype != torch.bfloat16 or C.dtype != want_c:
-                raise HipExtensionError(f"GroupedGemm problem {i}: A, B bf16 and C {want_c} expected")
-            opt = {k: pr.get(k) for k in ("bias", "res", "aux_in", "aux_out", "colsum")}
-            a_ext = ((M - 1) * lda + K) * 2
-            b_ext = ((K - 1) * ldb + N) * 2 if layout == GEMM_NN else ((N - 1) * ldb + K) * 2
-            if a_ext > A.numel() * 2 or b_ext > B.numel() * 2 or ((M - 1) * ldc + N) > C.numel():
-                raise HipExtensionError(f"GroupedGemm problem {i}: shape ({M}, {N}, {K}) does not fit its buffers")
-            arr[i] = _MhGemmProblem(A.data_ptr(), B.data_ptr(), C.data_ptr(),
-                                    *[(t.data_ptr() if t is not None else None) for t in opt.values()],
-                                    M, N, K, lda, ldb, ldc, pr.get("ldr", 0), pr.get("ldaux", 0), flags, a_ext, b_ext, 0)
-            self.keep += [A, B, C] + [t for t in opt.values() if t is not None]
-            shapes.append((M, N, K, not (flags & COLSUM)))
-        _check(lib().mh_gemm_grouped_check(_I(layout), arr, _I(len(problems))), "mh_gemm_grouped_check")
-        items, self.makespan = plan_grouped_tiles(shapes, self.n_workers, split)
-        import numpy as np
-        enc = np.empty((len(items), 2), dtype=np.uint32)
-        for k, (pi, tt, m0, n0) in enumerate(items):
-            if m0 // 64 > 0xffff or n0 // 64 > 0xffff:
-                raise HipExtensionError("GroupedGemm: tile origin beyond the work-item encoding")
-            enc[k] = (pi | (tt << 16), (m0 // 64) | ((n0 // 64) << 16))
-        self.items = torch.from_numpy(enc.view(np.int32)).to(device)
-        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
-        self.n_items = len(items)
-        self.flops = sum(2.0 * s[0] * s[1] * s[2] for s in shapes)
-        self.ideal = sum(s[0] * s[1] * s[2] for s in shapes) / (65536.0 * max(s[2] for s in shapes)) / self.n_workers
-        self.shapes = shapes
-
-    def launch(self) -> None:
-        ev = None
-        if _timer is not None:
-            ev = _timer.record(f"gemm_persist_kernel<{_LAYOUT_NAME[self.layout]}>", self.flops,
-                               ("grouped", tuple((s[0], s[1], s[2]) for s in self.shapes)))
-            ev[0].record()
-        call("mh_gemm_grouped", _I(self.layout), self.table, _I(self.n), self.items, _I(self.n_items), _I(self.n_workers))
-        if ev is not None:
-            ev[1].record()
 
 
 # ------------------------------------------------------------------------------------------------ fp8 path (C5)

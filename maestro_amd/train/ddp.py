@@ -86,6 +86,11 @@ class GradSync:
         self.bucket = max(1, bucket_bytes // (2 if self.half else flat_grad.element_size()))
         self._stage: dict = {}
         self.launched: list[tuple[int, int]] = []
+        # mode "rs_ag": the bucket plan of the FIRST exchange is replayed by every later one (``_calls`` = the (lo, hi) ranges handed
+        # to ``_launch``, in order), whatever the timing of the ``ready`` calls -- a step with the gradient hook and an accumulated
+        # step without it then cut the buffer at the same places, and the optimizer moments of a chunk never change owner.
+        self.plan: list[tuple[int, int]] | None = None
+        self._calls: list[tuple[int, int]] = []
         self.begin()
 
     def begin(self) -> None:
@@ -95,6 +100,7 @@ class GradSync:
             self.ready_iv.append((self.payload, self.grad.numel()))
         self.works = []
         self.launched = []
+        self._calls = []
 
     # ---- mode "rs_ag" (reduce-scatter + all-gather instead of an all-reduce; reference site
     # maestro/conf/trainer.py:9-14).  Every bucket is reduce-SCATTERED in place: rank r ends up with the SUM of chunk r of the
@@ -151,9 +157,34 @@ class GradSync:
             w.wait()
         return changed
 
+    def gather_pieces(self, flat: torch.Tensor, shift: int = 0) -> None:
+        """All-gather, piece by piece, a tensor that is sharded like the gradient buffer but covers only the window
+        ``[shift, shift + flat.numel())`` of it (the optimizer moments of a trainable span that does not start at 0): every scattered
+        piece goes through a temporary of the piece's size, so the equal chunks of the collective never depend on where the window
+        cuts a piece.  Checkpoint path (blocking, a copy per piece); ``gather_params`` is the in-place form for full-size buffers."""
+        n = flat.numel()
+        for lo, hi, a, b in self.owned():
+            if (lo, hi) not in self._scattered or not self.exchange:
+                continue
+            w_lo, w_hi = max(lo, shift), min(hi, shift + n)
+            if w_hi <= w_lo:
+                continue
+            tmp = torch.zeros(hi - lo, dtype=flat.dtype, device=flat.device)
+            s, e = max(a, shift), min(b, shift + n)
+            if e > s:
+                tmp[s - lo: e - lo].copy_(flat[s - shift: e - shift])
+            if self._host_staged(tmp):
+                host = tmp.cpu()
+                dist.all_gather_into_tensor(host, host[a - lo: b - lo].clone(), group=self.group)
+                tmp.copy_(host)
+            else:
+                dist.all_gather_into_tensor(tmp, tmp[a - lo: b - lo].clone(), group=self.group)
+            flat[w_lo - shift: w_hi - shift].copy_(tmp[w_lo - lo: w_hi - lo])
+
     def _launch(self, lo: int, hi: int) -> None:
         if hi <= lo:
             return
+        self._calls.append((lo, hi))
         self.launched.append((lo, hi))
         if not self.exchange:
             return
@@ -207,9 +238,21 @@ class GradSync:
         """Engine hook: ``grad[lo:hi]`` will not be written again in this backward."""
         self.ready_iv.append((lo, hi))
         start = self._contiguous_start()
+        if self.plan is not None:            # rs_ag, second exchange on: the recorded cuts
+            self._replay_plan(start)
+            return
         if self.frontier - start >= self.bucket:
             self._launch(start, self.frontier)
             self.frontier = start
+
+    def _replay_plan(self, start: int) -> None:
+        """Launch every recorded bucket whose range ``[lo, frontier)`` is complete (``lo >= start``), in the recorded order."""
+        while len(self._calls) < len(self.plan):
+            lo, hi = self.plan[len(self._calls)]
+            if hi != self.frontier or lo < start:
+                break
+            self._launch(lo, hi)
+            self.frontier = lo
 
     def _contiguous_start(self) -> int:
         """Lowest offset s such that [s, frontier) is fully covered by ready intervals."""
@@ -224,8 +267,12 @@ class GradSync:
 
     def finish(self) -> float:
         """Launch what is left, wait for all buckets; returns the factor that turns the sum into the mean."""
+        if self.plan is not None:
+            self._replay_plan(0)             # everything is final now: the rest of the recorded plan
         self._launch(0, self.frontier)
         self.frontier = 0
+        if self.mode == "rs_ag" and self.plan is None:
+            self.plan = list(self._calls)
         for w in self.works:
             self._wait(w)
         self.works = []

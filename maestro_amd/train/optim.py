@@ -102,7 +102,7 @@ class FusedAdamW:
         if getattr(self, "_owned", None) not in (None, owned):
             raise hip.HipExtensionError("FusedAdamW.step_sharded: the bucket plan changed between steps -- the moments of a chunk "
                                         "would move to another rank")
-        self._owned = owned
+        self._owned, self._sharded_world, self._gathered = owned, sync.world, False
         self.t += 1
         lr = self.lr if lr is None else lr
         lo, hi = self.lo, self.hi
@@ -118,20 +118,35 @@ class FusedAdamW:
         st.mark_synced()
         self.engine._pack_conv_weights()
 
-    def gather_state(self, sync) -> None:
-        """Under ``rs_ag``: assemble the full moments on every rank (all-gather of the owned chunks; for checkpoints)."""
-        if self.lo != 0:
-            raise NotImplementedError("gather_state: sharded moments are only laid out for a trainable span that starts at 0")
-        sync.gather_params(self.m)
-        sync.gather_params(self.v)
+    def gather_state(self, sync, base: int = 0) -> None:
+        """Under ``rs_ag``: assemble the full moments on every rank (a COLLECTIVE: all-gather of the owned chunks; for checkpoints).
+        ``base``: offset of ``sync``'s buffer inside the store's flat layout (``SupervisedLoop`` hands ``GradSync`` the slice
+        ``grad_all[lo:]``); the moments cover ``[self.lo, self.hi)`` of that layout, wherever the span starts."""
+        for buf in (self.m, self.v):
+            sync.gather_pieces(buf, shift=self.lo - base)
+        self._gathered = True
 
     def state_dict(self) -> dict:
-        return {"m": self.m, "v": self.v, "t": self.t, "lr": self.lr}
+        """The optimizer state for a checkpoint.  Under ``exchange_mode="rs_ag"`` a rank holds real moments only on its own chunks
+        (zeros elsewhere): saving that as it stands would silently drop (world - 1) / world of the Adam state, so an ungathered
+        sharded state is REFUSED here -- call ``gather_state(sync)`` on every rank first (``PretrainLoop.state_dict()`` does)."""
+        sharded = getattr(self, "_owned", None) is not None and getattr(self, "_sharded_world", 1) > 1
+        if sharded and not getattr(self, "_gathered", False):
+            raise hip.HipExtensionError("FusedAdamW.state_dict: the moments are sharded over the ranks (exchange_mode='rs_ag') and have "
+                                        "not been gathered since the last step: call gather_state(sync) on EVERY rank first "
+                                        "(PretrainLoop.state_dict() does)")
+        return {"m": self.m, "v": self.v, "t": self.t, "lr": self.lr, "span": (self.lo, self.hi),
+                "exchange_mode": "rs_ag" if sharded else "all_reduce", "world": getattr(self, "_sharded_world", 1), "gathered": True}
 
     def load_state_dict(self, sd: dict) -> None:
+        if not sd.get("gathered", True):
+            raise hip.HipExtensionError("FusedAdamW.load_state_dict: this state was saved from sharded, ungathered moments")
+        if "span" in sd and tuple(sd["span"]) != (self.lo, self.hi):
+            raise hip.HipExtensionError(f"FusedAdamW.load_state_dict: state of span {tuple(sd['span'])}, optimizer of span {(self.lo, self.hi)}")
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.t, self.lr = sd["t"], sd["lr"]
+        self._gathered = True      # full moments on this rank: under rs_ag the next step simply keeps using its own chunks
 
 
 class EngineAdamW(torch.optim.AdamW):

@@ -70,6 +70,18 @@ class PretrainLoop:
             self.engine._opt = None
         self.it = 0
 
+    def state_dict(self) -> dict:
+        """Loop state for a checkpoint (a COLLECTIVE under ``exchange_mode="rs_ag"``: call it on every rank -- the sharded moments
+        are all-gathered first, so that whichever rank writes the file writes the whole Adam state)."""
+        self.flush()
+        if self.sync is not None and self.sync.mode == "rs_ag" and getattr(self.opt, "_owned", None) is not None:
+            self.opt.gather_state(self.sync)
+        return {"optimizer": self.opt.state_dict(), "it": self.it, "exchange_mode": self.exchange_mode, "world": self.world}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.opt.load_state_dict(sd["optimizer"])
+        self.it = sd["it"]
+
     def flush(self) -> None:
         """Apply the optimizer update still queued for the next forward (no-op when nothing is pending)."""
         if self.overlap:

@@ -35,9 +35,4 @@ for (B, N, H, D) in SHAPES:  # noqa: N806
     tb = timed(lambda: hip.attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, D ** -0.5, variant=1))
     fl = B * H * N * N * D
     line = f"B {B:3d} N {N:5d} H {H:2d} D {D:2d}: fwd {tf:7.1f} us {4 * fl / tf / 1e6:7.1f} TF | bwd two kernels {tb:7.1f} us {10 * fl / tb / 1e6:7.1f} TF"
-    if D == 32 and N <= 1024:
-        ref = dqkv.clone()
-        ts = timed(lambda: hip.attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, D ** -0.5, variant=2))
-        rel = ((dqkv.float() - ref.float()).norm() / ref.float().norm()).item()
-        line += f" | single pass {ts:7.1f} us {10 * fl / ts / 1e6:7.1f} TF ({100 * (ts / tb - 1):+5.1f} %, rel diff {rel:.1e})"
     print(line, flush=True)

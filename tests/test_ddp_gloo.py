@@ -8,6 +8,14 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+
+def _free_port() -> int:
+    """A TCP port nobody listens on right now (fixed pid-derived ports collided between tests of one process: EADDRINUSE)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,7 +42,7 @@ def _worker(rank, world, port, out):
 def test_gradsync_two_ranks():
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
@@ -71,7 +79,7 @@ def test_gradsync_split_finish_two_ranks():
     """The optimizer may start on [split, n) while the head bucket [0, split) is still in flight."""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_split_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
@@ -235,7 +243,7 @@ def _slot_worker(rank, world, port, out):
 def test_loss_slot_bf16_buckets_callback_and_metric_two_ranks():
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 33500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_slot_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
@@ -311,7 +319,7 @@ def _rs_ag_worker(rank, world, port, out):
 def test_reduce_scatter_all_gather_plan_two_ranks():
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 33500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_rs_ag_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
@@ -341,3 +349,58 @@ def test_rs_ag_without_a_group_owns_everything():
         GradSync(g, mode="ring")
     with pytest.raises(ValueError):
         GradSync(g, mode="rs_ag", bucket_dtype=torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 5: under rs_ag the bucket plan of the first exchange is replayed by every later one whatever the timing of
+# the ``ready`` calls (a hooked step and an accumulated step cut the buffer alike), and a tensor sharded like the gradient buffer
+# but covering only a WINDOW of it (the moments of a trainable span that does not start at 0) gathers piece by piece.
+def _plan_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from maestro_amd.train.ddp import GradSync
+    n, slot = 64 * 40, 64
+    buf = torch.zeros(n + slot)
+    sync = GradSync(buf, bucket_bytes=4 * 64 * 12, always_ready_from=n, mode="rs_ag")
+    timings = [[(64 * 30, n), (64 * 17, 64 * 30), (64 * 10, 64 * 17), (0, 64 * 10)],      # the hooked step
+               [],                                                                         # an accumulated step: nothing before finish()
+               [(64 * 35, n), (64 * 33, 64 * 35), (64 * 5, 64 * 33), (0, 64 * 5)]]         # other segment boundaries
+    plans, sums = [], []
+    for t, ready in enumerate(timings):
+        buf[:n] = torch.arange(n, dtype=torch.float32) * (rank + 1) + t
+        buf[n] = float(rank)
+        sync.begin()
+        for lo, hi in ready:
+            sync.ready(lo, hi)
+        sync.finish()
+        owned = sync.owned()
+        plans.append(owned)
+        ok = all(torch.equal(buf[a:b], torch.arange(a, b, dtype=torch.float32) * 3 + 2 * t) for lo, hi, a, b in owned)
+        sums.append(ok)
+    # a window of the buffer: "moments" of the span [shift, shift + w), real on the owned chunks only
+    shift, w = 64 * 7 + 32, 64 * 21
+    full = torch.arange(n, dtype=torch.float32) + 0.5
+    mine = torch.zeros(w)
+    for lo, hi, a, b in plans[0]:
+        s, e = max(a, shift), min(b, shift + w)
+        if e > s:
+            mine[s - shift: e - shift] = full[s:e]
+    sync.gather_pieces(mine, shift=shift)
+    out.put((rank, plans[0] == plans[1] == plans[2], all(sums), torch.equal(mine, full[shift: shift + w]), len(plans[0])))
+    dist.destroy_process_group()
+
+
+def test_rs_ag_plan_is_replayed_and_windows_gather():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same_plan, sums_ok, window_ok, pieces in res:
+        assert same_plan, f"rank {rank}: the bucket plan moved between exchanges"
+        assert sums_ok and window_ok and pieces >= 3, (rank, sums_ok, window_ok, pieces)

@@ -12,6 +12,14 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+
+def _free_port() -> int:
+    """A TCP port nobody listens on right now (fixed pid-derived ports collided between tests of one process: EADDRINUSE)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
 def _build(dev):
     import maestro_amd.conf as conf
     from maestro_amd.ssl.mae import mae_tiny
@@ -63,7 +71,7 @@ def test_two_ranks_stay_in_sync():
         pytest.skip("needs a GPU")
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 29700 + os.getpid() % 1000
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
@@ -183,11 +191,36 @@ def _rs_ag_worker(rank, world, port, out, steps):
                          whole=sum(hi - lo for lo, hi, a, b in owned if (a, b) == (lo, hi)), buckets=len(loop.sync.launched),
                          loss_mean=float(loop.loss_mean.item()))
         if mode == "rs_ag":      # the moments: owner-only until gathered; afterwards equal on both ranks
-            loop.opt.gather_state(loop.sync)
+            from maestro_amd import hip
+            try:                 # an ungathered sharded state must not be saved as if it were whole
+                loop.opt.state_dict()
+                refused = False
+            except hip.HipExtensionError:
+                refused = True
+            sd = loop.state_dict()          # the collective form: gathers, then returns the whole Adam state on every rank
             m = loop.opt.m.cpu()
             allm = [torch.zeros_like(m) for _ in range(world)]
             dist.all_gather(allm, m)
             res[mode]["moments_same"] = all(torch.equal(allm[0], x) for x in allm) and float(m.abs().sum()) > 0
+            # save -> load into a FRESH loop (same weights) -> both continue: an accumulated step (no hook: the recorded bucket plan
+            # is replayed) and a plain one; parameters must stay equal
+            ds2, model2 = _build_single_groups()
+            loop2 = PretrainLoop(model2, 2, dev, total_steps=50, world_size=world, bucket_mb=1, base_lr=2e-3, exchange_mode=mode)
+            loop2.engine.store.flat.copy_(loop.engine.store.flat)
+            from maestro_amd.train.ddp import resync_engine
+            resync_engine(loop2.engine)
+            loop2.load_state_dict({k: (v if k != "optimizer" else {kk: (vv.clone() if isinstance(vv, torch.Tensor) else vv) for kk, vv in v.items()})
+                                   for k, v in sd.items()})
+            cont = []
+            for lp in (loop, loop2):
+                torch.manual_seed(555 + rank)
+                lp.step([batch, batch])
+                lp.step(batch)
+                torch.cuda.synchronize()
+                cont.append(lp.engine.store.flat.cpu())
+            drift = ((cont[0] - cont[1]).double().norm() / cont[0].double().norm()).item()
+            res[mode].update(refused=refused, resumed_rel=drift, state_keys=sorted(sd["optimizer"]))
+            del loop2
         del loop
     rel = ((res["rs_ag"]["flat"] - res["all_reduce"]["flat"]).double().norm() / res["all_reduce"]["flat"].double().norm()).item()
     moved = ((res["all_reduce"]["flat"] - res["rs_ag"]["flat"]).abs().max().item())
@@ -203,7 +236,7 @@ def test_reduce_scatter_all_gather_plan_equals_the_all_reduce_plan():
         pytest.skip("needs a GPU")
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 25500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_rs_ag_worker, args=(r, 2, port, out, 4)) for r in range(2)]
     for p in procs:
         p.start()
@@ -219,6 +252,9 @@ def test_reduce_scatter_all_gather_plan_equals_the_all_reduce_plan():
     for rank, r, rel, moved in res:
         assert r["rs_ag"]["same"] and r["all_reduce"]["same"], (rank, "parameters differ between the ranks")
         assert r["rs_ag"]["half_ok"] and r["rs_ag"]["moments_same"], rank
+        assert r["rs_ag"]["refused"], "FusedAdamW.state_dict() handed out sharded, ungathered moments"
+        assert r["rs_ag"]["resumed_rel"] < 1e-6, (rank, r["rs_ag"]["resumed_rel"])     # (atomically accumulated bias gradients: not bit-equal)
+        assert {"exchange_mode", "world", "gathered", "span"} <= set(r["rs_ag"]["state_keys"])
         # all of the payload but the short rest of every bucket (< 64 x world elements each) went through the reduce-scatter
         assert r["rs_ag"]["sharded"] > 0 and r["rs_ag"]["whole"] < 128 * r["rs_ag"]["buckets"], (rank, r["rs_ag"])
         assert r["all_reduce"]["sharded"] == 0
@@ -234,7 +270,7 @@ def test_full_plan_two_ranks_equal_the_concatenated_batch(bucket_dtype):
     steps = 5
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 30900 + os.getpid() % 1000 + (7 if bucket_dtype == "bf16" else 0)
+    port = _free_port()
     procs = [ctx.Process(target=_plan_worker, args=(r, 2, port, out, bucket_dtype, steps)) for r in range(2)]
     for p in procs:
         p.start()
@@ -348,7 +384,7 @@ def test_lightning_surface_overlapped_exchange_two_ranks():
     import numpy as np
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 31900 + os.getpid() % 1000
+    port = _free_port()
     procs = [ctx.Process(target=_lightning_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()

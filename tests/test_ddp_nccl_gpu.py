@@ -14,6 +14,14 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+
+def _free_port() -> int:
+    """A TCP port nobody listens on right now (fixed pid-derived ports collided between tests of one process: EADDRINUSE)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -60,7 +68,7 @@ def test_two_ranks_over_rccl():
         pytest.skip("needs two GPUs (one rank per GPU over RCCL)")
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 30700 + os.getpid() % 1000
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
@@ -101,7 +109,7 @@ def _bench_child(extra, launcher):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MAESTRO_WARM_PASSES="0")
     cmd = [sys.executable]
     if launcher:
-        port = 26500 + os.getpid() % 2000 + launcher
+        port = _free_port()
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                 "--master-port", str(port)]
     cmd += [str(root / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "3", "--batch", "8", "--cpu-seconds", "0",

@@ -279,114 +279,3 @@ def test_gemm_other_tile_heights(tile_name, layout, shape):
             outs.append(C)
         torch.cuda.synchronize()
         assert torch.equal(outs[0], outs[1]), (flags, (outs[0].float() - outs[1].float()).abs().max().item())
-
-
-# ------------------------------------------------------------------------------------------------------------------
-# Split-K with the in-kernel fix-up (mh_gemm_bf16_ws, round 4): outputs with few 128 x 128 tiles and a long K (the ViT-L fc2 /
-# fc1-dgrad of a small token group: 40-112 tiles for 256 CUs; the s2 encoder's M = 3200 long-K GEMMs).  Every workgroup stores its
-# fp32 partial, the last to arrive sums them in split order and runs the epilogue.  (Rule: <= 128 tiles and K >= 2048.)
-_SPLITK_SHAPES = [(576, 1024, 4096), (1152, 1024, 3072), (1024, 768, 3072), (200, 136, 2048), (1792, 1024, 4096), (130, 520, 2048)]
-
-
-def _splits_of(hip, layout, M, N, K, flags):  # noqa: N803
-    import ctypes
-    f = hip.lib().mh_gemm_splitk_workspace
-    f.restype = ctypes.c_long
-    return int(f(hip._I(layout), hip._I(M), hip._I(N), hip._I(K), hip._I(flags)))
-
-
-@pytest.mark.parametrize("layout", [0, 1])
-@pytest.mark.parametrize("shape", _SPLITK_SHAPES)
-def test_gemm_split_k_fixup_exact_integers(layout, shape, monkeypatch):
-    from maestro_amd import hip
-    dev = _dev()
-    M, N, K = shape
-    monkeypatch.setenv("MH_GEMM_SPLITK", "1")          # (opt-in: profiles/r04_splitk.txt)
-    assert _splits_of(hip, layout, M, N, K, 0) > 0, "this shape should be split"
-    assert _splits_of(hip, layout, 3200, 768, 3072, 0) == 0 and _splits_of(hip, layout, 576, 1024, 1024, 0) == 0     # 150 tiles / short K: not split
-    A, B, want = _operands(layout, M, N, K, dev, integer=True)
-    for rep in range(3):            # the arrival counters must be back at zero after every launch
-        C = torch.full((M, N), float("nan"), device=dev)
-        hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], C, N, hip.OUT_F32)
-        torch.cuda.synchronize()
-        assert torch.equal(C, want), f"rep {rep}: max diff {(C - want).abs().max().item()}"
-    Cb = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
-    hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], Cb, N, 0)
-    torch.cuda.synchronize()
-    assert torch.equal(Cb, want.bfloat16())
-    # ... and bit-identical to the unsplit kernel on random data?  No: another summation order.  But deterministic:
-    A, B, _ = _operands(layout, M, N, K, dev, integer=False)
-    outs = []
-    for _ in range(3):
-        C = torch.empty((M, N), device=dev)
-        hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], C, N, hip.OUT_F32)
-        torch.cuda.synchronize()
-        outs.append(C)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "the fix-up must sum the partials in a fixed order"
-    monkeypatch.setenv("MH_GEMM_SPLITK", "0")
-    C0 = torch.empty((M, N), device=dev)
-    hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], C0, N, hip.OUT_F32)
-    torch.cuda.synchronize()
-    assert (outs[0] - C0).abs().max() < 2e-5 * K ** 0.5
-
-
-def test_gemm_split_k_fixup_epilogues_and_shared_workspace(monkeypatch):
-    """Every epilogue the step runs on such shapes, against the unsplit launch (MH_GEMM_SPLITK=0) on integer data (bit-exact), with
-    problems of DIFFERENT shapes alternating on one stream -- they share the stream's workspace and its arrival counters."""
-    from maestro_amd import hip
-    dev = _dev()
-
-    def run(M, N, K, layout):  # noqa: N803
-        g = torch.Generator().manual_seed(5 + M + layout)           # (the same bias / residual in the split and the unsplit run)
-        A, B, want = _operands(layout, M, N, K, dev, integer=True)
-        bias = torch.randint(-2, 3, (N,), generator=g).float().to(dev)
-        res = torch.randint(-4, 5, (M, N), generator=g).float().to(dev)
-        out = {}
-        c = torch.empty((M, N), device=dev)
-        hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], c, N, hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=bias, res=res, ldr=N)
-        out["f32_res"] = c
-        cb, aux = torch.empty((M, N), device=dev, dtype=torch.bfloat16), torch.empty((M, N), device=dev, dtype=torch.uint8)
-        hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], cb, N, hip.BIAS | hip.GELU | hip.AUX_DGELU | hip.AUX_U8, bias=bias,
-                 aux_out=aux, ldaux=N)
-        out["gelu"], out["gelu_aux"] = cb, aux
-        cm, colsum = torch.empty((M, N), device=dev, dtype=torch.bfloat16), torch.zeros(((M + 63) // 64, N), device=dev)
-        hip.gemm(layout, M, N, K, A, A.shape[1], B, B.shape[1], cm, N, hip.MULAUX | hip.AUX_U8 | hip.COLSUM, aux_in=aux, ldaux=N,
-                 colsum=colsum)
-        out["mulaux"], out["colsum"] = cm, colsum
-        torch.cuda.synchronize()
-        return out, want
-
-    shapes = [(576, 1024, 4096, 0), (1152, 1024, 3072, 1), (200, 136, 2048, 0), (576, 1024, 4096, 1)]
-    monkeypatch.setenv("MH_GEMM_SPLITK", "1")
-    got = [run(*s) for s in shapes] + [run(*s) for s in shapes[:2]]
-    assert hip._splitk_ws, "the split launches should have taken a workspace"
-    monkeypatch.setenv("MH_GEMM_SPLITK", "0")
-    ref = [run(*s) for s in shapes] + [run(*s) for s in shapes[:2]]
-    for (a, want), (b, _), s in zip(got, ref, shapes + shapes[:2]):
-        for k in a:
-            x, y = a[k], b[k]
-            same = torch.equal(x.view(torch.int16), y.view(torch.int16)) if x.dtype == torch.bfloat16 else torch.equal(x, y)
-            assert same, (s, k)
-
-
-def test_gemm_split_k_fixup_inside_a_graph(monkeypatch):
-    """Captured and replayed (the engine's steady state): the workspace exists from the eager warm-up launch, the counters reset."""
-    from maestro_amd import hip
-    dev = _dev()
-    monkeypatch.setenv("MH_GEMM_SPLITK", "1")
-    M, N, K = 576, 1024, 4096
-    A, B, want = _operands(0, M, N, K, dev, integer=True)
-    C = torch.zeros((M, N), device=dev)
-    s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        hip.gemm(0, M, N, K, A, K, B, K, C, N, hip.OUT_F32)            # eager: allocates this stream's workspace
-        torch.cuda.synchronize()
-        gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr, stream=s):
-            for _ in range(3):
-                hip.gemm(0, M, N, K, A, K, B, K, C, N, hip.OUT_F32)
-    for _ in range(3):
-        C.fill_(float("nan"))
-        gr.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(C, want)

@@ -339,27 +339,6 @@ def test_reference_written_checkpoint_loads_without_the_reference(golden_dir, tm
     assert all(torch.equal(a, b) for a, b in zip(again.state_dict().values(), mod.state_dict().values()))
 
 
-def test_scheduler_covers_every_output_once():
-    import numpy as np
-
-    from maestro_amd import hip
-    rng = np.random.default_rng(0)
-    for _ in range(200):
-        shapes = [(int(rng.integers(1, 40)) * 8 * int(rng.integers(1, 30)), int(rng.integers(1, 200)) * 8,
-                   32 * int(rng.integers(2, 30)), bool(rng.integers(0, 2))) for _ in range(int(rng.integers(1, 5)))]
-        workers = int(rng.choice([8, 16, 64, 256]))
-        items, makespan = hip.plan_grouped_tiles(shapes, workers, rng.choice([None, 1, 2, 4]))
-        for pi, (M, N, K, quarter_ok) in enumerate(shapes):  # noqa: N806
-            cov = np.zeros(((M + 127) // 128, (N + 127) // 128), int)
-            for p, tt, m0, n0 in items:
-                if p == pi:
-                    h, w = hip._GTILE_SHAPE[tt]
-                    assert m0 % 64 == 0 and n0 % 64 == 0 and (quarter_ok or tt != hip.GTILE_128)
-                    cov[m0 // 128: (m0 + h) // 128, n0 // 128: (n0 + w) // 128] += 1
-            assert (cov == 1).all(), (shapes, workers)
-        assert makespan > 0
-
-
 def test_module_log_helpers_and_state_dict_surface():
     """``log_metric`` / ``log_step`` (``maestro/train/base.py:153-187``) forward to ``self.log`` with the reference's arguments;
     the autograd anchor of the engine bridge is neither a parameter nor a state-dict entry (Lightning's own checkpoints then

@@ -113,22 +113,12 @@ def _attn_ref(qkv, scale):
     return o.transpose(1, 2).reshape(B, N, H * D), torch.logsumexp(s, -1)
 
 
-# variant 1: two kernels (dQ; dK / dV), 2: the single-pass kernel (round 4: one workgroup per (batch, head), dQ in an LDS image;
-# D = 32 only) -- every shape class of that kernel: one / several 256-key blocks, a partial last key block and a partial last wave
-# of it, partial query tiles (incl. fewer tiles than the prefetch depth), both image sizes, N at the LDS limit (1024), several
-# heads sharing 128-byte lines; 0: the library's rule
-@pytest.mark.parametrize("variant", [1, 2, 0])
 @pytest.mark.parametrize("B,N,H,D", [(2, 100, 3, 64), (1, 256, 2, 64), (2, 470, 1, 64), (2, 16, 3, 64),
                                      (1, 1024, 2, 32), (3, 50, 4, 32), (2, 225, 2, 32), (1, 129, 1, 32),
                                      (2, 356, 3, 64), (1, 448, 2, 64), (2, 144, 2, 64), (1, 400, 4, 32), (1, 513, 2, 32),
                                      (2, 257, 3, 32), (1, 1000, 1, 32), (1, 33, 2, 32), (1, 288, 1, 64), (2, 64, 2, 32), (1, 96, 1, 32), (1, 768, 3, 32)])
-def test_attention_fwd_bwd(dev, B, N, H, D, variant):
+def test_attention_fwd_bwd(dev, B, N, H, D):
     from maestro_amd import hip
-    if variant == 2 and not (D == 32 and N <= 1024):
-        with pytest.raises(hip.HipExtensionError):
-            z = torch.zeros(1, device=dev)
-            hip.attn_bwd(z, z, z, z, z, z, B, N, H, D, 1.0, variant=2)
-        return
     qkv = (_rand(B, N, 3, H, D, seed=N + D) * 1.5).to(dev).bfloat16()
     scale = D**-0.5
     out = torch.zeros(B, N, H * D, device=dev, dtype=torch.bfloat16)
@@ -141,7 +131,7 @@ def test_attention_fwd_bwd(dev, B, N, H, D, variant):
     dout = _rand(B, N, H * D, seed=7).to(dev).bfloat16()
     delta = torch.zeros(B, H, N, device=dev)
     dqkv = torch.full((B, N, 3, H, D), float("nan"), device=dev, dtype=torch.bfloat16)
-    hip.attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale, variant=variant)
+    hip.attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, scale)
     want.backward(dout.float())
     err = (dqkv.float() - ref.grad).abs().max().item()
     assert err < 3e-2 * max(1.0, ref.grad.abs().max().item()), err
