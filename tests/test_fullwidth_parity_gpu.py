@@ -43,6 +43,12 @@ def _rel(a, b):
 # than on the 3-layer small model of tests/test_fp8_gpu.py (1.7e-4 / 5.6e-2 / 8.7e-2): twelve layers of per-tensor-scaled e4m3
 # operands (3 mantissa bits, <= 6 % per element) against an fp32 oracle; the bf16 engine on the same case sits at 3.5e-4 / 7e-3 / 1.5e-2.
 FP8_LOSS_TOL, FP8_PIX_TOL, FP8_GRAD_TOL = 9.4e-3, 1.44e-1, 3.76e-1
+# relative L2 of the residual stream after every stack (group encoders, joint encoder, group decoders) against the oracle's, <= 2x the
+# observed worst (round 5, profiles/r05_observed_errors.jsonl): bf16 4.7e-3 ... 6.2e-3 on every configuration (worst: C4's joint
+# encoder); fp8 6.2e-2 ... 7.4e-2 per group stack and 9.3e-2 / 1.04e-1 after the joint encoder (plain / stress inputs) -- uniform
+# over the stacks, so a single mis-scaled layer (one stack at several times its neighbours' error) fails here long before it
+# would reach the 0.376 end-to-end gradient bound
+BF16_HID_TOL, FP8_HID_TOL = 1.25e-2, 2e-1
 
 
 @pytest.mark.parametrize("config,B,dtype,stress", [("c3", 2, "bf16", False), ("c2", 2, "bf16", False), ("c3p", 1, "bf16", False),
@@ -68,6 +74,7 @@ def test_engine_matches_oracle_at_full_width(config, B, dtype, stress, observed)
             batch[m] = stress_raster(batch[m], c.patch_size.mae, g)
     fp8 = dtype == "fp8"
     LOSS_TOL, PIX_TOL, GRAD_TOL = (FP8_LOSS_TOL, FP8_PIX_TOL, FP8_GRAD_TOL) if fp8 else (BF16_LOSS_TOL, BF16_PIX_TOL, BF16_GRAD_TOL)  # noqa: N806
+    HID_TOL = FP8_HID_TOL if fp8 else BF16_HID_TOL  # noqa: N806
     eng = model.engine(B, dev, loss="l2_norm", dtype="fp8" if fp8 else None)
     assert (eng.fp8 is not None) == fp8 and (not fp8 or all(st.f8 is not None for st in eng._all_stacks()))
     torch.manual_seed(17)
@@ -78,8 +85,26 @@ def test_engine_matches_oracle_at_full_width(config, B, dtype, stress, observed)
     torch.cuda.synchronize()
     pixels, masks = eng.reconstructions()
 
+    # per-stack hidden states (round 5): the residual stream that enters every Transformer's final LayerNorm -- group encoders,
+    # joint encoder, group decoders -- so that ONE bad fp8 scale (or one wrong layer) shows at the stack where it happens instead
+    # of hiding under the end-to-end gradient tolerance
+    hidden = {}
+
+    def grab(name):
+        def hook(mod, args):       # (returns None: a pre-hook's return value would REPLACE the module's input)
+            hidden.setdefault(name, args[0].detach().clone())
+        return hook
+
+    hooks = []
+    for g in eng.groups:
+        hooks.append(oracle.encoder[g.model].norm.register_forward_pre_hook(grab(f"enc.{g.name}")))
+        hooks.append(oracle.decoder[g.model].norm.register_forward_pre_hook(grab(f"dec.{g.name}")))
+    if oracle.encoder_inter is not None:
+        hooks.append(oracle.encoder_inter.norm.register_forward_pre_hook(grab("joint")))
     ob, orec, omsk, _ = oracle({k: v.clone() for k, v in batch.items()}, "pretrain", noise=noise,
                                struct_masks={g: s[:, :, None] for g, s in struct.items()})
+    for h in hooks:
+        h.remove()
     oloss = om.compute_loss_rec(ob, orec, omsk, oracle.out_grid_size, om.norm_bands_of(ds.dataset), "l2_norm")
     oracle.zero_grad()
     oloss.backward()
@@ -90,6 +115,18 @@ def test_engine_matches_oracle_at_full_width(config, B, dtype, stress, observed)
         e = _rel(pixels[m].cpu(), orec[m].detach())
         observed(tag, f"pixels/{m}", e)
         assert e < PIX_TOL, (m, e)
+    stacks = {f"enc.{g.name}": eng.enc[g.name] for g in eng.groups}
+    stacks.update({f"dec.{g.name}": eng.dec[g.name] for g in eng.groups})
+    if eng.joint is not None:
+        stacks["joint"] = eng.joint
+    assert set(stacks) == set(hidden), (sorted(stacks), sorted(hidden))
+    worst_h = (0.0, None)
+    for name, st in stacks.items():
+        want = hidden[name].reshape(-1, hidden[name].shape[-1])
+        e = _rel(st.x_last.cpu(), want)
+        observed(tag, f"hidden/{name}", e)
+        worst_h = max(worst_h, (e, name))
+        assert e < HID_TOL, (name, e)
     e = abs(loss.item() - oloss.item()) / abs(oloss.item())
     observed(tag, "loss", e)
     assert e < LOSS_TOL, (loss.item(), oloss.item())
@@ -108,7 +145,7 @@ def test_engine_matches_oracle_at_full_width(config, B, dtype, stress, observed)
         checked += 1
     observed(tag, f"grad_worst/{worst[1]}", worst[0])
     assert checked == len(ograds) and checked > 100
-    print(f"[{tag}] loss hip={loss.item():.6f} oracle={oloss.item():.6f}; worst gradient rel L2 {worst}")
+    print(f"[{tag}] loss hip={loss.item():.6f} oracle={oloss.item():.6f}; worst gradient rel L2 {worst}; worst hidden state {worst_h}")
     if fp8:
         # second forward: the activation scales now come from the first step's absmax (delayed scaling) -- under the stress inputs
         # that is where a mis-derived scale (heavy tails, constant patches) would show
