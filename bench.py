@@ -288,7 +288,19 @@ def main() -> None:
     torch.manual_seed(42)            # identical initial weights on every rank (the loops also broadcast rank 0's)
     ds, model = build_model(args.config, args.phase)
     torch.manual_seed(42 + rank)     # per-rank mask draws from here on
+    # Gradient exchange plan at N > 1 (DESIGN §6 "exchange budget"): configurations whose optimizer traffic is a large share of the step
+    # (>= 300 M parameters: C3', C4, C5 -- 1.3-3.6 GB of fp32 gradients, AdamW 1.6-4.5 ms per step) take reduce-scatter -> AdamW on the
+    # rank's 1 / N chunk -> all-gather (same bytes on the links as the all-reduce, (N - 1) / N of the optimizer pass saved on every
+    # rank); the smaller ones (C2, C3: AdamW 0.5-0.9 ms) keep the all-reduce with the AdamW-overlapped tail bucket.  --exchange-mode
+    # overrides; fp8 keeps the all-reduce (the e4m3 shadows of foreign chunks would need their scales).
+    n_params = sum(p.numel() for p in model.parameters())
+    exchange_mode, exchange_why = args.exchange_mode, "--exchange-mode"
+    if exchange_mode is None:
+        big = n_params >= 300e6 and args.dtype != "fp8" and not args.overlap_optimizer
+        exchange_mode = "rs_ag" if (big and (world > 1 or args.rehearse_exchange or args.rehearse_dry)) else "all_reduce"
+        exchange_why = (f"{n_params / 1e6:.0f} M parameters " + (">= 300 M: sharded optimizer pass" if big else "< 300 M (or fp8): all-reduce, tail bucket under AdamW"))
     if args.phase == "pretrain":
+        args.exchange_mode = exchange_mode
         loop = PretrainLoop(model, args.batch, dev, loss=args.loss, total_steps=args.steps + args.warmup, world_size=world,
                             exchange=True if (args.rehearse_exchange or args.rehearse_dry) else None,
                             overlap_optimizer=args.overlap_optimizer, dtype=args.dtype, exchange_mode=args.exchange_mode)
@@ -389,7 +401,8 @@ def main() -> None:
                        "parallelism": f"dp{world}", "params_M": round(loop.engine.store.total / 1e6, 1),
                        "final_loss": round(loss_val, 5), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
                        "warm_passes": getattr(warm_engine, "warm_passes_run", 0),     # the passes that actually ran (0 under fp8 / overlap)
-                       "exchange": (getattr(loop, "exchange_mode", "all_reduce") if getattr(loop, "sync", None) is not None else "none")},
+                       "exchange": (getattr(loop, "exchange_mode", "all_reduce") if getattr(loop, "sync", None) is not None else "none"),
+                       "exchange_rule": exchange_why if getattr(loop, "sync", None) is not None else "one GPU: no exchange"},
             "whole_step": {"train_gflop_per_tile": w["gflop_tile"],
                            "mfma_frac": round(value / world * w["gflop_tile"] / 1e3 / MFMA_PEAK_TFLOPS, 4)},
         }

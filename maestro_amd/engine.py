@@ -728,6 +728,7 @@ class MAEEngine(EngineBase):
             from maestro_amd.fp8 import Fp8Plan
             self.fp8 = Fp8Plan(device, self.store.total)
         self._alloc()
+        self._alloc_mask_upload()
         if self.fp8 is not None:
             self.fp8.finalize()
         self.store.refresh_half(force=True)
@@ -762,9 +763,7 @@ class MAEEngine(EngineBase):
             date_row = torch.cat([(s.date_off + torch.arange(s.n_tok) // s.L).to(I32) for s in g.mods])
             pos_dec = torch.cat([m.pos_dec_rows[s.name].repeat(s.D, 1) for s in g.mods], dim=0)
             self.gb[g.name] = dict(
-                xg=e(Bn, L, E), dxg=z(Bn, L, E), noise_h=[torch.empty(Bn, L, dtype=F32).pin_memory() for _ in range(RING)],
-                struct_h=[torch.empty(Bn, L, dtype=U8).pin_memory() for _ in range(RING)], noise=e(Bn, L),
-                struct=e(Bn, L, dt=U8),
+                xg=e(Bn, L, E), dxg=z(Bn, L, E),       # (noise / struct + their pinned ring slots: views, see _alloc_mask_upload)
                 vis=e(Bn, N, dt=I32), msk=e(Bn, g.k, dt=I32), inv=e(Bn, L, dt=I32), mask=e(Bn, L, dt=U8),
                 dates=z(Bn, n_dates, 8), n_dates=n_dates, tok_slot=tok_slot.to(dev), date_row=date_row.to(dev),
                 pos_dec=pos_dec.to(dev).contiguous(), tok_table=e(len(g.mods), Dd),
@@ -788,6 +787,24 @@ class MAEEngine(EngineBase):
         srcs = {s.src: s for s in self.mods.values()}            # weight = D*H*W per MODALITY (model.py:239), band-groups share it
         tot_w = sum(s.Dates * s.L for s in srcs.values())
         self.loss_w = {n: (s.Dates * s.L) / tot_w for n, s in srcs.items()}
+
+    def _alloc_mask_upload(self) -> None:
+        """The per-step host draws (noise f32 [Beff, L] + structural mask u8 [Beff, L] per group) as ONE flat byte buffer: a pinned
+        ring on the host, a staging ring and the live buffer on the device; ``gb[g]["noise" | "struct"]`` and their ``_h`` ring slots
+        are views (256-byte aligned segments)."""
+        segs, off = [], 0
+        for g in self.groups:
+            for key, dt, esz in (("noise", F32, 4), ("struct", U8, 1)):
+                n = g.Beff * g.L * esz
+                segs.append((g.name, key, dt, off, n, (g.Beff, g.L)))
+                off += (n + 255) // 256 * 256
+        self._mask_dev = torch.zeros(off, dtype=U8, device=self.device)
+        self._mask_stage = [torch.zeros(off, dtype=U8, device=self.device) for _ in range(RING)]
+        self._mask_host = [torch.zeros(off, dtype=U8).pin_memory() for _ in range(RING)]
+        self._upload_stream = torch.cuda.Stream(device=self.device)
+        for name, key, dt, o, n, shape in segs:
+            self.gb[name][key] = self._mask_dev[o: o + n].view(dt).view(shape)
+            self.gb[name][key + "_h"] = [h[o: o + n].view(dt).view(shape) for h in self._mask_host]
 
     def _pack_conv_weights(self, fp8_done: bool = False) -> None:
         """Derived weight copies beyond the flat bf16 shadow (called wherever the shadows are refreshed: engine start,
@@ -900,8 +917,17 @@ class MAEEngine(EngineBase):
                 n_g, s_g = self._reference_tie_order(g, gbuf, n_g, s_g, slot)
             nh.copy_(n_g)
             sh.copy_(s_g)
-            gbuf["noise"].copy_(nh, non_blocking=True)
-            gbuf["struct"].copy_(sh, non_blocking=True)
+        # ONE host -> device copy of all groups' draws, on the upload stream, into this slot's device staging buffer; the main stream
+        # waits for it with an event and moves it into the (graph-visible) mask buffers with one device -> device copy (round 5: one
+        # pinned copy per step instead of two per group; end of step t -> first forward kernel of step t + 1: 28 -> 23 us by HIP
+        # events, scripts/r05_boundary.py.  The ~90 us gap that rocprofv3 traces show at this boundary is the profiler's own).
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self._upload_stream):
+            self._mask_stage[slot].copy_(self._mask_host[slot], non_blocking=True)
+            up = torch.cuda.Event()
+            up.record(self._upload_stream)
+        main.wait_event(up)
+        self._mask_dev.copy_(self._mask_stage[slot], non_blocking=True)
         if self._opt is not None:      # overlapped optimizer: this step's scalars (or "nothing pending") ride the same ring
             hh = self._opt_hyper_h[slot]
             hh.copy_(torch.tensor(self._opt_pending if self._opt_pending is not None else [0.0] * 5, dtype=F32))
