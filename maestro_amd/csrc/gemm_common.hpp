@@ -124,24 +124,42 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
     if (out_f32) {
         // fp32 output straight from the accumulators: lane (lm, g) owns 4 consecutive columns of row 16i + lm in every
         // n-tile, i.e. 16-byte accesses that four lanes extend to a 64-byte row segment; no LDS round trip.
+        // Round 5: the residual rows of FOUR row blocks (16 loads) are requested before the first store.  The compiler cannot prove
+        // that `res` and `C` do not overlap, so with the loads of row block i + 1 written behind the stores of row block i it kept
+        // them there: MT dependent memory round trips per workgroup (8 on the 256 x 256 tile), each a full HBM latency inside the
+        // step, where the residual stream of a layer is cold -- the decoder fc2 launch spent 38 of its 125 us in this epilogue.
+        f32x4 bias4[4];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int m = m_base + 16 * i + lm;
-            f32x4 add[4];
+        for (int j = 0; j < 4; ++j) {
+            const int n = n_base + 16 * j + 4 * g;
+            bias4[j] = (f32x4){0, 0, 0, 0};
+            if ((p.flags & MH_GEMM_BIAS) && n < p.N) bias4[j] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        }
+        constexpr int IB = MT % 4 == 0 ? 4 : MT % 3 == 0 ? 3 : MT;      // row blocks per batch of residual loads (16 IB registers)
+        static_assert(MT % IB == 0, "row blocks per wave");
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n_base + 16 * j + 4 * g;
-                add[j] = (f32x4){0, 0, 0, 0};
-                if (m < p.M && n < p.N) {
-                    if (p.flags & MH_GEMM_BIAS) add[j] = *reinterpret_cast<const f32x4*>(p.bias + n);
-                    if (p.flags & MH_GEMM_RESIDUAL) add[j] += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n);
+        for (int i0 = 0; i0 < MT; i0 += IB) {
+            f32x4 add[IB][4];
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii) {
+                const int m = m_base + 16 * (i0 + ii) + lm;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n_base + 16 * j + 4 * g;
+                    add[ii][j] = bias4[j];
+                    if ((p.flags & MH_GEMM_RESIDUAL) && m < p.M && n < p.N)
+                        add[ii][j] += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n_base + 16 * j + 4 * g;
-                if (m < p.M && n < p.N)
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = acc[j][i] * alpha + add[j];
+            for (int ii = 0; ii < IB; ++ii) {
+                const int m = m_base + 16 * (i0 + ii) + lm;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n_base + 16 * j + 4 * g;
+                    if (m < p.M && n < p.N)
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = acc[j][i0 + ii] * alpha + add[ii][j];
+                }
             }
         }
         return;
@@ -149,6 +167,30 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
     f32x4 cs_lo = {0, 0, 0, 0}, cs_hi = {0, 0, 0, 0};   // MH_GEMM_COLSUM: this lane's 8 columns summed over its rows
     const float s8 = p.c8 ? *p.c8_scale : 0.f;
     float amax8 = 0.f;
+    // The saved GELU' bytes (or pre-activations) of ALL passes are requested before the first store (round 5: behind the stores of
+    // pass p the compiler could not move the loads of pass p + 1 -- aux_in / C may overlap for all it knows -- and every pass waited
+    // for a cold load AND for the previous pass's stores to complete).
+    u32x4 aux_all[NPASS][SUB];
+    {
+        const int n = n_base + (l & 7) * 8;
+        if (p.flags & (MH_GEMM_DGELU | MH_GEMM_MULAUX)) {
+#pragma unroll
+            for (int pass_m = 0; pass_m < NPASS; ++pass_m)
+#pragma unroll
+                for (int pass = 0; pass < SUB; ++pass) {
+                    const int m = m_base + RP * pass_m + pass * 8 + (l >> 3);
+                    aux_all[pass_m][pass] = (u32x4){0, 0, 0, 0};
+                    if (m < p.M && n < p.N) {
+                        if (p.flags & MH_GEMM_AUX_U8) {
+                            const u32x2 b8 = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint8_t*>(p.aux_in) + (size_t)m * p.ldaux + n);
+                            aux_all[pass_m][pass] = (u32x4){b8[0], b8[1], 0, 0};
+                        } else {
+                            aux_all[pass_m][pass] = *reinterpret_cast<const u32x4*>(p.aux_in + (size_t)m * p.ldaux + n);
+                        }
+                    }
+                }
+        }
+    }
 #pragma unroll
     for (int pass_m = 0; pass_m < NPASS; ++pass_m) {
 #pragma unroll
@@ -163,22 +205,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, const f
                 b_lo = *reinterpret_cast<const f32x4*>(p.bias + n);
                 b_hi = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
             }
-            u32x4 aux_pre[SUB];
-            if (p.flags & (MH_GEMM_DGELU | MH_GEMM_MULAUX)) {
-#pragma unroll
-                for (int pass = 0; pass < SUB; ++pass) {
-                    const int m = m_base + RP * pass_m + pass * 8 + (l >> 3);
-                    aux_pre[pass] = (u32x4){0, 0, 0, 0};
-                    if (m < p.M && n < p.N) {
-                        if (p.flags & MH_GEMM_AUX_U8) {
-                            const u32x2 b8 = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint8_t*>(p.aux_in) + (size_t)m * p.ldaux + n);
-                            aux_pre[pass] = (u32x4){b8[0], b8[1], 0, 0};
-                        } else {
-                            aux_pre[pass] = *reinterpret_cast<const u32x4*>(p.aux_in + (size_t)m * p.ldaux + n);
-                        }
-                    }
-                }
-            }
+            const u32x4 (&aux_pre)[SUB] = aux_all[pass_m];
 #pragma unroll
             for (int pass = 0; pass < SUB; ++pass) {
                 const int r = pass * 8 + (l >> 3), m = m_base + RP * pass_m + r;

@@ -296,12 +296,38 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
         kstep(kNext, integral_constant<int, 7>{});
         for (int kt = EPI_STEPS; kt < nk; ++kt) kstep(kNext, kNone);
     }
-    // ---- the last tile's epilogue is exposed
+    // ---- the last tile's epilogue is exposed.  Round 5: ALL its operand loads (residual rows / GELU' bytes / bias) are requested
+    // before the first store.  Written chunk by chunk (load, compute, store, load, ...) the compiler kept every chunk's loads behind
+    // the previous chunk's stores (it cannot prove that `res` / `aux_in` and `C` do not overlap): eight dependent memory round trips
+    // -- load latency + store completion, vmcnt(0) each -- at the end of every workgroup, ~10 us inside the step where the residual
+    // stream is cold, on launches whose workgroups own one or two tiles (out-proj, fc2: 384 tiles for 512 workgroups).
     epi_setup(cm0, cn0);
-    auto tail = [&](auto cc) { epi_loads(cc); epi_math(cc, acc); };
-    tail(integral_constant<int, 0>{}); tail(integral_constant<int, 1>{}); tail(integral_constant<int, 2>{});
-    tail(integral_constant<int, 3>{}); tail(integral_constant<int, 4>{}); tail(integral_constant<int, 5>{});
-    tail(integral_constant<int, 6>{}); tail(integral_constant<int, 7>{});
+    if constexpr (DIAG == 0 && (EPI == EPI_F32 || EPI == EPI_MULAUX)) {
+        u32x4 tx[8], ty[8];
+        f32x4 tbx[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, tby[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        auto fetch = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            epi_loads(cc);
+            tx[c] = ld_x; ty[c] = ld_y;
+            if constexpr ((c & 3) == 0) { tbx[c >> 2] = bias_x; tby[c >> 2] = bias_y; }
+        };
+        auto finish = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            ld_x = tx[c]; ld_y = ty[c]; bias_x = tbx[c >> 2]; bias_y = tby[c >> 2];
+            epi_math(cc, acc);
+        };
+        fetch(integral_constant<int, 0>{}); fetch(integral_constant<int, 1>{}); fetch(integral_constant<int, 2>{});
+        fetch(integral_constant<int, 3>{}); fetch(integral_constant<int, 4>{}); fetch(integral_constant<int, 5>{});
+        fetch(integral_constant<int, 6>{}); fetch(integral_constant<int, 7>{});
+        finish(integral_constant<int, 0>{}); finish(integral_constant<int, 1>{}); finish(integral_constant<int, 2>{});
+        finish(integral_constant<int, 3>{}); finish(integral_constant<int, 4>{}); finish(integral_constant<int, 5>{});
+        finish(integral_constant<int, 6>{}); finish(integral_constant<int, 7>{});
+    } else {
+        auto tail = [&](auto cc) { epi_loads(cc); epi_math(cc, acc); };
+        tail(integral_constant<int, 0>{}); tail(integral_constant<int, 1>{}); tail(integral_constant<int, 2>{});
+        tail(integral_constant<int, 3>{}); tail(integral_constant<int, 4>{}); tail(integral_constant<int, 5>{});
+        tail(integral_constant<int, 6>{}); tail(integral_constant<int, 7>{});
+    }
 }
 
 template <bool B_KMAJOR>
