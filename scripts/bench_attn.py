@@ -32,7 +32,7 @@ for (B, N, H, D) in SHAPES:  # noqa: N806
     lse, delta = torch.empty(B, H, N, device=dev), torch.empty(B, H, N, device=dev)
     dqkv = torch.empty_like(qkv)
     tf = timed(lambda: hip.attn_fwd(qkv, out, lse, B, N, H, D, D ** -0.5))
-    tb = timed(lambda: hip.attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, D ** -0.5, variant=1))
+    tb = timed(lambda: hip.attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, D, D ** -0.5))
     fl = B * H * N * N * D
     line = f"B {B:3d} N {N:5d} H {H:2d} D {D:2d}: fwd {tf:7.1f} us {4 * fl / tf / 1e6:7.1f} TF | bwd two kernels {tb:7.1f} us {10 * fl / tb / 1e6:7.1f} TF"
     print(line, flush=True)
