@@ -525,6 +525,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     u32x4 rq[2], rd[2];
     tile_load<D>(qb, rs, 0, N, rq);
     tile_load<D>(dob, os, 0, N, rd);
+    // lse / delta of the NEXT query tile travel with its Q / dO rows (round 5): fetched between the two barriers of the tile that
+    // needs them, as before, every workgroup sat through one dependent global-load latency per query tile with all four waves at
+    // the barrier (16 times per workgroup at N = 1024)
+    const float* const lse_bh = lse + ((size_t)b * H + h) * N;
+    const float* const dlt_bh = delta + ((size_t)b * H + h) * N;
+    float r_lse = 0.f, r_dlt = 0.f;       // (threads 0-63: the tile's query threadIdx.x)
+    auto stat_load = [&](int q0) {
+        if (threadIdx.x < 64) {
+            const int q = min(q0 + (int)threadIdx.x, N - 1);        // clamped: unconditional loads, validity applied when stored
+            r_lse = lse_bh[q];
+            r_dlt = dlt_bh[q];
+        }
+    };
+    stat_load(0);
     for (int it = 0; it < ntile; ++it) {
         const int q0 = it * 64;
         __syncthreads();
@@ -533,14 +547,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         tile_store_row<D>(do_row, rd);
         tile_store_tr<D>(do_tr, rd);
         if (threadIdx.x < 64) {
-            const int q = q0 + threadIdx.x;
-            s_lse[threadIdx.x] = q < N ? -lse[((size_t)b * H + h) * N + q] * LOG2E : -INFINITY;     // negated: S's initial accumulator
-            s_dlt[threadIdx.x] = q < N ? -delta[((size_t)b * H + h) * N + q] : 0.f;   // negated: dP - delta as a packed add
+            const bool valid = q0 + (int)threadIdx.x < N;
+            s_lse[threadIdx.x] = valid ? -r_lse * LOG2E : -INFINITY;     // negated: S's initial accumulator
+            s_dlt[threadIdx.x] = valid ? -r_dlt : 0.f;                   // negated: dP's initial accumulator
         }
         __syncthreads();
         if (it + 1 < ntile) {
             tile_load<D>(qb, rs, q0 + 64, N, rq);
             tile_load<D>(dob, os, q0 + 64, N, rd);
+            stat_load(q0 + 64);
         }
         if (k0 >= N) continue;
         // S[q][key], dP[q][key]: rows = queries 16*qt + 4g + r, col = key
