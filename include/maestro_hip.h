@@ -354,10 +354,6 @@ int mh_bce_loss(const float* logits, const float* target, float missing_val, flo
 int mh_colsum(const void* x, int x_is_f32, float* out, int M, int N, int ld, void* stream);
 /* Zero n_spans (offset, length) float ranges of one buffer (spans: device array of 2*n_spans longs; max_len = longest span).
  * Used to clear only the atomically accumulated gradient slots when the weight gradients are stored by the grouped GEMM. */
-/* Read `bytes` bytes at p and discard them (16-byte aligned base; a tail < 16 bytes is not read): brings a weight matrix into the
- * Infinity Cache ahead of the GEMM that streams it as its B operand (the nn.Linear weights of vit_pytorch's Attention / FeedForward,
- * call sites maestro/ssl/mae.py:135-174).  No output, no side effect on memory contents. */
-int mh_touch(const void* p, long bytes, void* stream);
 int mh_zero_spans(float* base, const long* spans_device, int n_spans, long max_len, void* stream);
 /* x[0..n) *= *scale with the scalar read on the device; a no-op when it equals 1 (the autograd bridge of the Lightning
  * surface, maestro/train/base.py:242-247: loss.backward() hands over d loss as a device tensor). */

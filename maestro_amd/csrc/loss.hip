@@ -300,30 +300,6 @@ extern "C" int mh_zero_spans(float* base, const long* spans_device, int n_spans,
     return 0;
 }
 
-// Read-and-discard sweep: pulls a weight matrix from HBM into the Infinity Cache (and the reading XCDs' L2) shortly before the GEMM
-// that streams it.  Why it exists (round 5, profiles/r05_gap_table.md): every XCD sweeps the WHOLE B operand of a forward / dgrad
-// GEMM, so an HBM-cold weight matrix costs a 42 us launch +11 us although it is only 4.7 MB -- the workgroups of all XCDs miss on
-// the same panels at the same tile transitions, beyond what their two-step operand prefetch covers.
-__global__ __launch_bounds__(256) void touch_kernel(const u32x4* __restrict__ p, long n16) {
-    const long stride = (long)gridDim.x * 256;
-    u32x4 acc = {0, 0, 0, 0};
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
-        const u32x4 v = p[i];   // default cache policy: the point is that the lines STAY in the Infinity Cache (a nontemporal load does not keep them)
-        acc |= v;
-    }
-    asm volatile("" ::"v"(acc));   // the loads must not be optimised away; nothing is stored
-}
-
-extern "C" int mh_touch(const void* p, long bytes, void* stream) {
-    MH_CHECK_ARG(p && bytes > 0 && ((uintptr_t)p % 16) == 0, "mh_touch: bad arguments (16-byte aligned base)");
-    const long n16 = bytes / 16;
-    if (n16 == 0) return 0;
-    const int grid = (int)std::min<long>(ceil_div(n16, 256 * 4), 1024);
-    hipLaunchKernelGGL(touch_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4*)p, n16);
-    MH_LAUNCH_CHECK();
-    return 0;
-}
-
 extern "C" int mh_cast_bf16(const float* src, void* dst, long n, void* stream) {
     MH_CHECK_ARG(src && dst && n > 0, "mh_cast_bf16: bad arguments");
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(ceil_div(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);

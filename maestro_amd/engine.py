@@ -130,9 +130,6 @@ class ParamStore:
 
 
 # ======================================================================================= transformer stack
-_TOUCH_W = int(os.environ.get("MAESTRO_TOUCH_W", "0"))   # experiment (round 5): bit 0 forward, bit 1 backward: mh_touch of a GEMM's weights ahead of it
-
-
 class Stack:
     """Buffers and launch sequence for one ``Transformer`` (pre-LN blocks, fp32 residual stream, bf16 GEMMs)."""
 
@@ -222,21 +219,13 @@ class Stack:
                 self._forward_layer_fp8(l, attn, ff, s, x_in, x_mid, x_out)
                 continue
             proj = attn.to_out[0]
-            if _TOUCH_W & 1:
-                hip.touch(ps.h(attn.to_qkv.weight))
             hip.layernorm_fwd(x_in, M, 0, attn.norm.weight, attn.norm.bias, s["h1"], M, 0, s["mean1"], s["rstd1"], 1, M, dim)
             hip.gemm(hip.GEMM_NT, M, 3 * inner, dim, s["h1"], dim, ps.h(attn.to_qkv.weight), dim, s["qkv"], 3 * inner)
-            if _TOUCH_W & 1:
-                hip.touch(ps.h(proj.weight))
             hip.attn_fwd(s["qkv"], s["o"], s["lse"], self.Bn, self.N, self.H, self.Dh, attn.scale)
             hip.gemm(hip.GEMM_NT, M, dim, inner, s["o"], inner, ps.h(proj.weight), inner, x_mid, dim,
                      hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=proj.bias, res=x_in, ldr=dim)
             ln2, fc1, fc2 = ff.net[0], ff.net[1], ff.net[4]
-            if _TOUCH_W & 1:
-                hip.touch(ps.h(fc1.weight))
             hip.layernorm_fwd(x_mid, M, 0, ln2.weight, ln2.bias, s["h2"], M, 0, s["mean2"], s["rstd2"], 1, M, dim)
-            if _TOUCH_W & 1:
-                hip.touch(ps.h(fc2.weight))
             # s["hpre"] receives GELU'(pre-activation): the forward epilogue has the CDF / PDF at hand, the backward multiplies
             hip.gemm(hip.GEMM_NT, M, mlp, dim, s["h2"], dim, ps.h(fc1.weight), dim, s["act"], mlp,
                      hip.BIAS | hip.GELU | hip.AUX_DGELU | eng.aux_flag, bias=fc1.bias, aux_out=s["hpre"], ldaux=mlp)
@@ -338,9 +327,6 @@ class Stack:
                              aux_in=s["hpre"], ldaux=mlp, colsum=s["cs"] if defer else self.cs_ws, c8=f["dh8"], ldc8=mlp,
                              c8_scale=plan.g_scale(f["g_dh"]), c8_amax=plan.g_amax(f["g_dh"]))
             else:
-                if _TOUCH_W & 2:
-                    hip.touch(ps.h(fc2.weight))
-                    hip.touch(ps.h(fc1.weight))
                 hip.gemm(hip.GEMM_NN, M, mlp, dim, cur16, dim, ps.h(fc2.weight), mlp, dh, mlp, hip.MULAUX | hip.COLSUM | eng.aux_flag,
                          aux_in=s["hpre"], ldaux=mlp, colsum=s["cs"] if defer else self.cs_ws)
                 if f is not None:
@@ -367,8 +353,6 @@ class Stack:
                 hip.gemm_fp8(M, inner, dim, f["mid8"], dim, f["wt_proj"], dim, self.do, inner, plan.g_descale(f["g_mid"]),
                              plan.w_descale(f["sw_proj"]), a_format=hip.FP8_E5M2)
             else:
-                if _TOUCH_W & 2:
-                    hip.touch(ps.h(proj.weight))
                 hip.gemm(hip.GEMM_NN, M, inner, dim, mid16, dim, ps.h(proj.weight), inner, self.do, inner)
             if not defer:
                 hip.gemm(hip.GEMM_TN, dim, inner, M, mid16, dim, s["o"], inner, ps.g(proj.weight), inner, AT)
@@ -381,8 +365,6 @@ class Stack:
                 hip.gemm_fp8(M, dim, 3 * inner, f["dqkv8"], 3 * inner, f["wt_qkv"], 3 * inner, self.dh2, dim,
                              plan.g_descale(f["g_dqkv"]), plan.w_descale(f["sw_qkv"]), a_format=hip.FP8_E5M2)
             else:
-                if _TOUCH_W & 2:
-                    hip.touch(ps.h(attn.to_qkv.weight))
                 hip.gemm(hip.GEMM_NN, M, dim, 3 * inner, dqkv, 3 * inner, ps.h(attn.to_qkv.weight), dim, self.dh2, dim)
             prev_fc2_bias = ps.g(self.t.layers[l - 1][1].net[4].bias) if l > 0 else None  # = colsum(dx_out of layer l-1)
             if defer:

@@ -532,11 +532,6 @@ def bce_loss(logits, target, missing_val, acc, dlogits, B, C):  # noqa: N803
     call("mh_bce_loss", logits, target, _F(float(missing_val)), acc, dlogits, _I(B), _I(C))
 
 
-def touch(t) -> None:
-    """Read-and-discard sweep of a contiguous tensor (``mh_touch``): warms the Infinity Cache with a weight matrix."""
-    call("mh_touch", t, ctypes.c_long(t.numel() * t.element_size()))
-
-
 def zero_spans(base, spans, n_spans, max_len):
     call("mh_zero_spans", base, spans, _I(n_spans), _L(max_len))
 
