@@ -223,6 +223,7 @@ static int gemm_dispatch(int tile, int layout, int M, int N, int K, const void* 
                          const void* aux_in, void* aux_out, int ldaux, float* colsum, void* stream) {
     MH_CHECK_ARG(tile >= MH_TILE_AUTO && tile <= MH_TILE_REG_192, "mh_gemm_bf16: tile %d", tile);
     MH_CHECK_ARG(layout >= 0 && layout <= 2, "mh_gemm_bf16: layout %d", layout);
+    MH_CHECK_ARG(!(flags & ~0x7ff), "mh_gemm_bf16: unknown flag bits 0x%x", flags & ~0x7ff);
     MH_CHECK_ARG(M > 0 && N > 0 && K > 0, "mh_gemm_bf16: empty problem %d %d %d", M, N, K);
     MH_CHECK_ARG(A && B && C, "mh_gemm_bf16: null operand");
     MH_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0, "mh_gemm_bf16: lda/ldb must be multiples of 8 (%d, %d)", lda, ldb);
