@@ -42,7 +42,10 @@ def make(M, N, K, swapped, tile, fl):  # noqa: N803
                             ldr=N if res is not None else 0, tile=tile)
 
 
-for (M, N, K) in ((8192, 768, 3072), (8192, 768, 768), (3200, 768, 3072), (3200, 768, 768), (11392, 768, 3072), (11392, 768, 768)):
+SHAPES = ((8192, 768, 3072), (8192, 768, 768), (3200, 768, 3072), (3200, 768, 768), (11392, 768, 3072), (11392, 768, 768))
+if len(sys.argv) > 1 and sys.argv[1] == 'wide':   # the wide outputs: is the 192-wide tile's lower operand traffic per FLOP worth anything where 128 x 128 already balances?
+    SHAPES = ((8192, 3072, 768), (8192, 2304, 768), (32768, 3072, 512), (32768, 1536, 512), (11392, 3072, 768))
+for (M, N, K) in SHAPES:
     for fl, fname in ((0, "plain"), (F32, "f32+res")):
         row = []
         cands = [("auto", False, None), ("reg128", False, hip.TILE_REG_128), ("pp128", False, hip.TILE_PP_128),
