@@ -269,8 +269,11 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
+        # the line's n_gpus / value are whole-job figures: a launcher that started another number of ranks than --gpus names would
+        # make them wrong silently -> refuse (non-zero exit) instead
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     ndev = torch.cuda.device_count()
     if args.backend == "nccl" and world > ndev:
         raise SystemExit(f"{world} ranks need {world} GPUs (found {ndev}); one process per GPU")
@@ -283,6 +286,8 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
 
     torch.set_num_threads(min(4, host_cores()))   # host-side torch ops are tiny (mask draws); a 128-thread pool only adds latency
     torch.manual_seed(42)            # identical initial weights on every rank (the loops also broadcast rank 0's)
@@ -295,6 +300,8 @@ def main() -> None:
     # overrides; fp8 keeps the all-reduce (the e4m3 shadows of foreign chunks would need their scales).
     n_params = sum(p.numel() for p in model.parameters())
     exchange_mode, exchange_why = args.exchange_mode, "--exchange-mode"
+    if exchange_mode is None and os.environ.get("MAESTRO_EXCHANGE"):      # flag > environment > rule
+        exchange_mode, exchange_why = os.environ["MAESTRO_EXCHANGE"], "MAESTRO_EXCHANGE"
     if exchange_mode is None:
         big = n_params >= 300e6 and args.dtype != "fp8" and not args.overlap_optimizer
         exchange_mode = "rs_ag" if (big and (world > 1 or args.rehearse_exchange or args.rehearse_dry)) else "all_reduce"
@@ -339,6 +346,9 @@ def main() -> None:
         loop.step(batch)
     flush()
     sync()
+    gsync = getattr(loop, "sync", None)
+    if gsync is not None:           # exchange statistics of the timed region only (the `comm` object of the line)
+        gsync.reset_stats(on=True)
     wait0 = getattr(loop.engine, "host_wait_s", 0.0)
     t0 = time.perf_counter()
     loss_log = []
@@ -365,6 +375,27 @@ def main() -> None:
     # Roofline leg: the same steps once more with HIP events around every MFMA-kernel launch on its stream (event
     # pairs cannot be recorded inside a captured graph, so these steps are launched eagerly; kernels are identical).
     timer = None if args.no_kernel_timing else hip.KernelTimer()
+    comm = None
+    if gsync is not None:
+        # Self-diagnosis of the data-parallel run (no scaling claim is made from it): which backend and how many ranks the process
+        # group really has, which exchange plan ran and why, what it moved per step and how long the step's main stream WAITED for
+        # collectives (HIP events around GradSync's waits: the exchange time that backward / AdamW did not hide).
+        rep = gsync.comm_report()
+        gsync.reset_stats(on=False)
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            rccl = None
+        comm = {"backend": dist.get_backend() if dist.is_initialized() else None,
+                "world_size": dist.get_world_size() if dist.is_initialized() else 1, "rccl_version": rccl,
+                "exchange": rep.pop("mode"), "exchange_rule": exchange_why, **rep,
+                "grad_mbytes": round(loop.engine.store.total * 4 / 1e6, 1),
+                "how": "per optimizer step over the timed region; exposed_ms = HIP events on the main stream around the waits for the "
+                       "buckets (all_reduce plan: the tail bucket's wait sits inside the two-part AdamW)"}
+        if world > 1:               # the slowest rank's exposure is the job's
+            t = torch.tensor([comm["exposed_ms_per_step"] or 0.0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            comm["exposed_ms_per_step_max_over_ranks"] = round(float(t.item()), 4)
     if timer is not None:
         saved_ms = loop.engine.multi_stream
         loop.engine.multi_stream = False   # one kernel at a time, so each event pair brackets exactly one launch
@@ -406,6 +437,8 @@ def main() -> None:
             "whole_step": {"train_gflop_per_tile": w["gflop_tile"],
                            "mfma_frac": round(value / world * w["gflop_tile"] / 1e3 / MFMA_PEAK_TFLOPS, 4)},
         }
+        if comm is not None:
+            out["comm"] = comm
         if args.log_losses:
             out["losses"] = [float(x.item()) for x in loss_log]
         if args.dtype == "fp8":

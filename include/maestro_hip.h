@@ -81,10 +81,28 @@ enum { MH_TILE_AUTO = -1, MH_TILE_REG_128 = 0, MH_TILE_DMA_256 = 1, MH_TILE_DMA_
        MH_TILE_PP_128_DIAG4 = 11, MH_TILE_PP_128_DIAG5 = 12,  /* full epilogue, other instruction placements */
        /* MH_TILE_REG_128's kernel with 64 x 128 tiles (three workgroups per CU) / 192 x 128 tiles: for outputs whose 128 x 128
         * tiling fills the chip's workgroup slots badly (N = 512 / 768).  NT / NN without MH_GEMM_COLSUM; otherwise = REG_128. */
-       MH_TILE_REG_64 = 13, MH_TILE_REG_192 = 14 };
+       MH_TILE_REG_64 = 13, MH_TILE_REG_192 = 14,
+       /* stream-K tiles (gemm_sk.hip; mh_gemm_bf16_sk only -- they need a workspace): 192 x 128 / 256 x 128, one workgroup per CU */
+       MH_TILE_SK_192 = 15, MH_TILE_SK_256 = 16 };
 int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                       int ldaux, float* colsum, void* stream);
+
+/* Stream-K GEMM (gemm_sk.hip): C[M, N] = A[M, K] B^T (layout 0, B [N, K]) or A B (layout 1, B [K, N]) with the long-K, narrow-N
+ * problems of the transformer blocks in mind (fc2, out-proj, fc1 / qkv / out-proj dgrads: the nn.Linear call sites of
+ * vit_pytorch's Attention / FeedForward built at maestro/ssl/mae.py:135-174).  `grid` persistent four-wave workgroups (one per
+ * CU: pass the CU count of the device, or of the stream's CU mask) split tiles x (K / 64) units evenly; a tile shared by
+ * several workgroups is summed in workgroup order by the one that owns its last K step (deterministic, no atomics on C).
+ *   tile   MH_TILE_SK_192 (192 x 128 x 64) or MH_TILE_SK_256 (256 x 128 x 64)
+ *   flags  0 (bf16 C) or MH_GEMM_OUT_F32 | MH_GEMM_BIAS | MH_GEMM_RESIDUAL (fp32 C = A B + bias + res); K %% 64 == 0, K >= 128,
+ *          N %% 128 == 0; anything else returns -2 (nothing launched, error string untouched): use mh_gemm_bf16
+ *   workspace  mh_gemm_sk_workspace(tile, grid) bytes, 16-byte aligned, owned by the caller, ZEROED ONCE before its first use (the
+ *          kernel leaves its flag words zero); launches that may run concurrently (different streams) need different workspaces.
+ * Same fp32 sums per output element as mh_gemm_bf16 when no tile is shared; a shared tile adds its K ranges in ascending order. */
+long mh_gemm_sk_workspace(int tile, int grid);
+int mh_gemm_bf16_sk(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                    int flags, const float* bias, const float* res, int ldr, void* workspace, long workspace_bytes, int grid,
+                    void* stream);
 
 /* Grouped weight-gradient GEMM: ONE launch over the 256x256 tiles of many independent "TN" problems
  * dW_i[M_i, N_i] (f32) = A_i^T B_i with A_i [K_i, M_i] bf16 (= dY_i), B_i [K_i, N_i] bf16 (= X_i), K_i = tokens.

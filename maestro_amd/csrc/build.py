@@ -26,7 +26,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-re
 # -fno-slp-vectorize + scalar source (ATTN_SCALAR_VALU, default 1): packed v_pk_fma_f32 / v_pk_add_f32 beside MFMAs are no faster
 # than two scalar instructions on gfx950 and measured 0-6 % slower here (scripts/bench_attn.py: backward N = 576, D = 32:
 # 160 -> 150 us; N = 1024: 379 -> 370; forward +-1 %).  MH_ATTN_FLAGS="-DATTN_SCALAR_VALU=0" rebuilds the packed form.
-FILE_FLAGS = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"] + os.environ.get("MH_ATTN_FLAGS", "").split()}
+FILE_FLAGS = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"] + os.environ.get("MH_ATTN_FLAGS", "").split(),
+              # gemm_sk.hip runs one wave per SIMD (512-register budget): without this flag the compiler selects the AGPR form of the
+              # MFMA, keeps the accumulators' loop phis in VGPRs and shuttles every accumulator through v_accvgpr_write / _read around
+              # each MFMA (774 moves in the kernel, 8 per MFMA in the K loop); with it the K loop has none.
+              "gemm_sk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:

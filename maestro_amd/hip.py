@@ -62,6 +62,7 @@ _I, _F, _L = ctypes.c_int, ctypes.c_float, ctypes.c_long
 TILE_AUTO, TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128, TILE_DMA_128x4 = -1, 0, 1, 2, 3, 4, 5
 TILE_DMA_256_LOCKSTEP = 6   # MH_TILE_DMA_256 without the wave-group stagger (A/B experiments)
 TILE_REG_64, TILE_REG_192 = 13, 14   # the register-staged kernel with 64 x 128 / 192 x 128 tiles
+TILE_SK_192, TILE_SK_256 = 15, 16   # stream-K tiles (gemm_sk.hip): routed to mh_gemm_bf16_sk with a per-stream workspace
 TILE_PP_128 = 7             # persistent 128x128 tile, epilogue of tile t inside the main loop of tile t + 1 (gemm_pp.hip)
 TILES = (TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128, TILE_DMA_128x4)
 _LAYOUT_NAME = {0: "NT", 1: "NN", 2: "TN"}
@@ -69,7 +70,8 @@ _TILE_NAME = {TILE_REG_128: "gemm_kernel<{}>", TILE_DMA_256: "gemm_dma_kernel<25
               TILE_DMA_256x128: "gemm_dma_kernel<256x128,{}>", TILE_DMA_128x256: "gemm_dma_kernel<128x256,{}>",
               TILE_DMA_128: "gemm_dma_kernel<128x128,{}>", TILE_DMA_128x4: "gemm_dma_kernel<128x128q,{}>",
               TILE_DMA_256_LOCKSTEP: "gemm_dma_kernel<256x256,{}>", TILE_PP_128: "gemm_pp_kernel<{}>",
-              TILE_REG_64: "gemm_kernel<{},64x128>", TILE_REG_192: "gemm_kernel<{},192x128>"}
+              TILE_REG_64: "gemm_kernel<{},64x128>", TILE_REG_192: "gemm_kernel<{},192x128>",
+              TILE_SK_192: "gemm_sk_kernel<{},192x128>", TILE_SK_256: "gemm_sk_kernel<{},256x128>"}
 _tile_choice: dict = {}     # (layout, M, N, K, flags) -> fastest tile, filled while tuning is on
 _tuning = False
 
@@ -136,7 +138,54 @@ def set_instep_tuner(t: InStepTuner | None) -> None:
     _instep = t
 
 
+# ---- stream-K GEMM (mh_gemm_bf16_sk): one workspace per (stream, tile, grid) -- launches on different streams may overlap and must not
+# share flag words or partial slots.  Zeroed once at allocation; the kernel leaves its flag words zero.  Allocated on first use, so the
+# first call of a new (stream, tile, grid) must be an eager one (the engine's warm-up passes run before any hipGraph capture).
+_sk_ws: dict = {}
+_sk_grid = None
+
+
+def sk_grid() -> int:
+    """Persistent workgroups of a stream-K launch: one per CU (MH_SK_GRID overrides, e.g. the CU count of a masked stream)."""
+    global _sk_grid
+    if _sk_grid is None:
+        env = os.environ.get("MH_SK_GRID")
+        _sk_grid = int(env) if env else torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    return _sk_grid
+
+
+def sk_workspace(tile: int, grid: int) -> torch.Tensor:
+    key = (torch.cuda.current_stream().cuda_stream, tile, grid)
+    ws = _sk_ws.get(key)
+    if ws is None:
+        lib().mh_gemm_sk_workspace.restype = ctypes.c_long
+        nbytes = lib().mh_gemm_sk_workspace(_I(tile), _I(grid))
+        if nbytes <= 0:
+            raise HipExtensionError(f"mh_gemm_sk_workspace({tile}, {grid}) = {nbytes}")
+        if torch.cuda.is_current_stream_capturing():
+            raise HipExtensionError("stream-K workspace requested for the first time inside a hipGraph capture: run the step eagerly once first")
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        _sk_ws[key] = ws
+    return ws
+
+
+def sk_error_flag(ws: torch.Tensor) -> int:
+    """1 if a finisher's wait for a partial ran into its bound in any launch that used this workspace (results are then wrong)."""
+    return int(ws[4092:4096].view(torch.int32).item())
+
+
+def gemm_sk(tile: int, layout: int, M: int, N: int, K: int, A, lda: int, B, ldb: int, C, ldc: int, flags: int = 0, bias=None,  # noqa: N803
+            res=None, ldr: int = 0, grid: int | None = None) -> int:
+    """Returns the library's code: 0 launched, -2 the problem is not served by the stream-K kernel (nothing launched)."""
+    grid = grid or sk_grid()
+    ws = sk_workspace(tile, grid)
+    return lib().mh_gemm_bf16_sk(_I(tile), _I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C), _I(ldc),
+                                 _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(ws), _L(ws.numel()), _I(grid), stream())
+
+
 def _gemm_tile(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum) -> int:  # noqa: N803
+    if tile in (TILE_SK_192, TILE_SK_256):
+        return gemm_sk(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr)
     return lib().mh_gemm_bf16_tile(_I(tile), _I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C),
                                    _I(ldc), _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux),
                                    ptr(colsum), stream())

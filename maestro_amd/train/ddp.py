@@ -86,11 +86,18 @@ class GradSync:
         self.bucket = max(1, bucket_bytes // (2 if self.half else flat_grad.element_size()))
         self._stage: dict = {}
         self.launched: list[tuple[int, int]] = []
-        # mode "rs_ag": the bucket plan of the FIRST exchange is replayed by every later one (``_calls`` = the (lo, hi) ranges handed
-        # to ``_launch``, in order), whatever the timing of the ``ready`` calls -- a step with the gradient hook and an accumulated
-        # step without it then cut the buffer at the same places, and the optimizer moments of a chunk never change owner.
-        self.plan: list[tuple[int, int]] | None = None
+        # mode "rs_ag": the buckets are cut at STATIC places -- [numel - (k + 1) bucket, numel - k bucket), launched once covered --
+        # a function of the buffer's size and the bucket size alone, whatever the timing of the ``ready`` calls: a step with the
+        # gradient hook, an accumulated step without it and the first step of a resumed loop all cut the buffer at the same places,
+        # and the optimizer moments of a chunk never change owner.  (Round 5 recorded the plan of the FIRST exchange instead: a first
+        # exchange without the hook froze a one-bucket plan and silently lost all overlap for the rest of the run.)
         self._calls: list[tuple[int, int]] = []
+        # exchange statistics of the bench line's ``comm`` object (``stats = True``): buckets and bytes per exchange, and the time the
+        # main stream spent WAITING for collectives (HIP events around the waits; with a host-blocking backend also the host's time)
+        self.stats = False
+        self._ev: list = []
+        self._host_wait_s = 0.0
+        self._n_exchanges = self._n_buckets = self._n_bytes = 0
         self.begin()
 
     def begin(self) -> None:
@@ -238,20 +245,20 @@ class GradSync:
         """Engine hook: ``grad[lo:hi]`` will not be written again in this backward."""
         self.ready_iv.append((lo, hi))
         start = self._contiguous_start()
-        if self.plan is not None:            # rs_ag, second exchange on: the recorded cuts
-            self._replay_plan(start)
+        if self.mode == "rs_ag":
+            self._static_buckets(start)
             return
         if self.frontier - start >= self.bucket:
             self._launch(start, self.frontier)
             self.frontier = start
 
-    def _replay_plan(self, start: int) -> None:
-        """Launch every recorded bucket whose range ``[lo, frontier)`` is complete (``lo >= start``), in the recorded order."""
-        while len(self._calls) < len(self.plan):
-            lo, hi = self.plan[len(self._calls)]
-            if hi != self.frontier or lo < start:
+    def _static_buckets(self, start: int) -> None:
+        """rs_ag: launch every static bucket ``[max(0, frontier - bucket), frontier)`` that is complete (``lo >= start``)."""
+        while self.frontier > 0:
+            lo = max(0, self.frontier - self.bucket)
+            if lo < start:
                 break
-            self._launch(lo, hi)
+            self._launch(lo, self.frontier)
             self.frontier = lo
 
     def _contiguous_start(self) -> int:
@@ -267,33 +274,77 @@ class GradSync:
 
     def finish(self) -> float:
         """Launch what is left, wait for all buckets; returns the factor that turns the sum into the mean."""
-        if self.plan is not None:
-            self._replay_plan(0)             # everything is final now: the rest of the recorded plan
+        if self.mode == "rs_ag":
+            self._static_buckets(0)          # everything is final now: the rest of the static cuts
         self._launch(0, self.frontier)
         self.frontier = 0
-        if self.mode == "rs_ag" and self.plan is None:
-            self.plan = list(self._calls)
-        for w in self.works:
-            self._wait(w)
+        self._wait_all(self.works)
         self.works = []
+        self._count_exchange()
         return 1.0 / self.world
+
+    def _wait_all(self, works) -> None:
+        """Wait for collectives; with ``stats`` the wait is bracketed by events on the current stream (an RCCL ``wait`` makes the
+        stream wait, not the host: the events' distance is the time the step was exposed to the exchange) and by the host clock."""
+        if not works:
+            return
+        if self.stats and self.grad.is_cuda:
+            import time
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for w in works:
+                self._wait(w)
+            e1.record()
+            self._host_wait_s += time.perf_counter() - t0
+            self._ev.append((e0, e1))
+            return
+        for w in works:
+            self._wait(w)
+
+    def reset_stats(self, on: bool = True) -> None:
+        self.stats, self._ev, self._host_wait_s = on, [], 0.0
+        self._n_exchanges = self._n_buckets = self._n_bytes = 0
+
+    def _count_exchange(self) -> None:
+        self._n_exchanges += 1
+        self._n_buckets += len(self._calls)
+        esz = 2 if self.half else self.grad.element_size()
+        self._n_bytes += sum(min(hi, self.payload) - lo for lo, hi in self._calls if min(hi, self.payload) > lo) * esz
+
+    def comm_report(self) -> dict:
+        """Averages per exchange since construction (synchronises the device to read the events)."""
+        n = max(self._n_exchanges, 1)
+        exposed = None
+        if self._ev:
+            torch.cuda.synchronize()
+            exposed = sum(a.elapsed_time(b) for a, b in self._ev) / n
+        return {"mode": self.mode, "bucket_mb": round(self.bucket * (2 if self.half else self.grad.element_size()) / 2 ** 20, 1),
+                "bucket_dtype": "bf16" if self.half else str(self.grad.dtype).replace("torch.", ""),
+                "exchanges": self._n_exchanges, "buckets_per_step": round(self._n_buckets / n, 2),
+                "mbytes_per_step": round(self._n_bytes / n / 1e6, 2),
+                "exposed_ms_per_step": None if exposed is None else round(exposed, 4),
+                "host_wait_ms_per_step": round(1e3 * self._host_wait_s / n, 4)}
 
     def finish_split(self):
         """Like ``finish`` but does not wait for the LAST bucket (the head of the flat buffer, which backward completes
         last and which therefore cannot overlap any compute): returns ``(scale, split, wait_tail)`` -- everything in
         ``[split, numel)`` is reduced; ``[0, split)`` is reduced once ``wait_tail()`` has been called.  The caller runs the
         optimizer on the upper part first, so the exposed all-reduce hides under it."""
+        if self.mode == "rs_ag":
+            raise RuntimeError("GradSync.finish_split: mode='rs_ag' cuts its buckets at static places (finish() + step_sharded); "
+                               "the split tail is an all-reduce plan")
         split = self.frontier
         self._launch(0, self.frontier)
         self.frontier = 0
         tail = self.works.pop() if (self.works and split > 0) else None
-        for w in self.works:
-            self._wait(w)
+        self._wait_all(self.works)
         self.works = []
+        self._count_exchange()
 
         def wait_tail():
             if tail is not None:
-                self._wait(tail)
+                self._wait_all([tail])
 
         return 1.0 / self.world, (split if tail is not None else 0), wait_tail
 

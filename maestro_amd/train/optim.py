@@ -135,12 +135,14 @@ class FusedAdamW:
             raise hip.HipExtensionError("FusedAdamW.state_dict: the moments are sharded over the ranks (exchange_mode='rs_ag') and have "
                                         "not been gathered since the last step: call gather_state(sync) on EVERY rank first "
                                         "(PretrainLoop.state_dict() does)")
-        return {"m": self.m, "v": self.v, "t": self.t, "lr": self.lr, "span": (self.lo, self.hi),
-                "exchange_mode": "rs_ag" if sharded else "all_reduce", "world": getattr(self, "_sharded_world", 1), "gathered": True}
+        # Sharded: hand out COPIES.  The live tensors stop being a whole state at the next step_sharded (owned chunks advance, the
+        # chunks gathered from other ranks go stale), and a deferred / asynchronous checkpoint writer holding them would save a
+        # mixed-step Adam state without any error.  ("t" stamps the step the copies belong to.)
+        m, v = (self.m.clone(), self.v.clone()) if sharded else (self.m, self.v)
+        return {"m": m, "v": v, "t": self.t, "lr": self.lr, "span": (self.lo, self.hi),
+                "exchange_mode": "rs_ag" if sharded else "all_reduce", "world": getattr(self, "_sharded_world", 1)}
 
     def load_state_dict(self, sd: dict) -> None:
-        if not sd.get("gathered", True):
-            raise hip.HipExtensionError("FusedAdamW.load_state_dict: this state was saved from sharded, ungathered moments")
         if "span" in sd and tuple(sd["span"]) != (self.lo, self.hi):
             raise hip.HipExtensionError(f"FusedAdamW.load_state_dict: state of span {tuple(sd['span'])}, optimizer of span {(self.lo, self.hi)}")
         self.m.copy_(sd["m"])

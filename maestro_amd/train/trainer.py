@@ -70,17 +70,31 @@ class PretrainLoop:
             self.engine._opt = None
         self.it = 0
 
-    def state_dict(self) -> dict:
-        """Loop state for a checkpoint (a COLLECTIVE under ``exchange_mode="rs_ag"``: call it on every rank -- the sharded moments
-        are all-gathered first, so that whichever rank writes the file writes the whole Adam state)."""
+    def gather_state(self) -> None:
+        """COLLECTIVE under ``exchange_mode="rs_ag"`` (call it on EVERY rank before ``state_dict()``): all-gathers the sharded
+        optimizer moments so that whichever rank writes the checkpoint holds the whole Adam state.  No-op otherwise."""
         self.flush()
         if self.sync is not None and self.sync.mode == "rs_ag" and getattr(self.opt, "_owned", None) is not None:
             self.opt.gather_state(self.sync)
-        return {"optimizer": self.opt.state_dict(), "it": self.it, "exchange_mode": self.exchange_mode, "world": self.world}
+
+    def state_dict(self) -> dict:
+        """Loop state for a checkpoint: optimizer moments, the fp32 master weights, the step counter.  NOT a collective: the usual
+        ``if rank == 0: save(loop.state_dict())`` is safe.  Under ``rs_ag`` every rank calls ``gather_state()`` first; an
+        ungathered sharded state is refused (``FusedAdamW.state_dict``) instead of hanging in a one-rank all-gather."""
+        self.flush()
+        return {"optimizer": self.opt.state_dict(), "params": self.engine.store.flat.detach().clone(), "it": self.it,
+                "exchange_mode": self.exchange_mode, "world": self.world}
 
     def load_state_dict(self, sd: dict) -> None:
+        """Restores moments, step counter and -- when the checkpoint carries them -- the fp32 masters with every derived copy
+        (bf16 shadows, packed conv weights, fp8 scales).  A state saved under another exchange mode or world size loads: the
+        moments in a checkpoint are always whole; under ``rs_ag`` the next step keeps using this rank's chunks of them."""
+        from maestro_amd.train.ddp import resync_engine
         self.opt.load_state_dict(sd["optimizer"])
         self.it = sd["it"]
+        if sd.get("params") is not None:
+            self.engine.store.flat.copy_(sd["params"])
+            resync_engine(self.engine)
 
     def flush(self) -> None:
         """Apply the optimizer update still queued for the next forward (no-op when nothing is pending)."""

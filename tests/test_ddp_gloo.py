@@ -340,11 +340,16 @@ def test_rs_ag_without_a_group_owns_everything():
     from maestro_amd.train.ddp import GradSync
     g = torch.zeros(640 + 64)
     sync = GradSync(g, bucket_bytes=4 * 128, always_ready_from=640, mode="rs_ag")
-    sync.begin()
-    sync.ready(320, 640)
-    sync.ready(0, 320)
-    assert sync.finish() == 1.0
-    assert sync.owned() == [(0, 320, 0, 320), (320, 640, 320, 640)] and sync.gather_params(torch.zeros(640)) == []
+    # static cuts (round 6): [numel - (k + 1) bucket, numel - k bucket) whatever the timing of the ready calls
+    want = [(0, 64, 0, 64)] + [(lo, lo + 128, lo, lo + 128) for lo in range(64, 576, 128)] + [(576, 640, 576, 640)]
+    for ready in ([(320, 640), (0, 320)], [], [(600, 640), (100, 600), (0, 100)]):
+        sync.begin()
+        for lo, hi in ready:
+            sync.ready(lo, hi)
+        assert sync.finish() == 1.0
+        assert sync.owned() == want and sync.gather_params(torch.zeros(640)) == []
+    with pytest.raises(RuntimeError):
+        sync.finish_split()                  # the split tail belongs to the all-reduce plan
     with pytest.raises(ValueError):
         GradSync(g, mode="ring")
     with pytest.raises(ValueError):
@@ -352,8 +357,8 @@ def test_rs_ag_without_a_group_owns_everything():
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# Round 5: under rs_ag the bucket plan of the first exchange is replayed by every later one whatever the timing of
-# the ``ready`` calls (a hooked step and an accumulated step cut the buffer alike), and a tensor sharded like the gradient buffer
+# Round 5 / 6: under rs_ag the buckets are cut at static places whatever the timing of the ``ready`` calls (a hooked
+# step, an accumulated step without the hook -- also as the FIRST exchange -- and other segment boundaries cut the buffer alike), and a tensor sharded like the gradient buffer
 # but covering only a WINDOW of it (the moments of a trainable span that does not start at 0) gathers piece by piece.
 def _plan_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

@@ -124,10 +124,16 @@ def test_one_rank_rccl_rehearsal_of_the_exchange_plan():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     plain = _bench_child([], 0)
-    assert plain["config"]["exchange"] == "none" and len(plain["losses"]) == 4
+    assert plain["config"]["exchange"] == "none" and len(plain["losses"]) == 4 and "comm" not in plain
     for k, mode in enumerate(("all_reduce", "rs_ag"), start=1):
         reh = _bench_child(["--rehearse-exchange", "--exchange-mode", mode], k)
         assert reh["config"]["exchange"] == mode and reh["n_gpus"] == 1
+        # the line's self-diagnosis of the exchange (round 6): what the process group really is, what the plan moved, how long the
+        # step's main stream waited for collectives
+        comm = reh["comm"]
+        assert comm["backend"] == "nccl" and comm["world_size"] == 1 and comm["exchange"] == mode and comm["rccl_version"]
+        assert comm["buckets_per_step"] >= 1 and comm["mbytes_per_step"] > 0.9 * comm["grad_mbytes"]
+        assert comm["exposed_ms_per_step"] is not None and 0.0 <= comm["exposed_ms_per_step"] < 50.0
         for a, b in zip(plain["losses"], reh["losses"]):
             assert a == a and abs(a - b) <= 1e-5 * abs(a), (mode, plain["losses"], reh["losses"])
         assert reh["losses"][-1] < reh["losses"][0]           # ... and it trains
