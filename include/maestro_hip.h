@@ -83,7 +83,8 @@ enum { MH_TILE_AUTO = -1, MH_TILE_REG_128 = 0, MH_TILE_DMA_256 = 1, MH_TILE_DMA_
         * tiling fills the chip's workgroup slots badly (N = 512 / 768).  NT / NN without MH_GEMM_COLSUM; otherwise = REG_128. */
        MH_TILE_REG_64 = 13, MH_TILE_REG_192 = 14,
        /* stream-K tiles (gemm_sk.hip; mh_gemm_bf16_sk only -- they need a workspace): 192 x 128 / 256 x 128, one workgroup per CU */
-       MH_TILE_SK_192 = 15, MH_TILE_SK_256 = 16 };
+       MH_TILE_SK_192 = 15, MH_TILE_SK_256 = 16,
+       MH_TILE_SK_DMA_256 = 17 /* 256 x 256 x 32, eight waves, the LDS-DMA ring of MH_TILE_DMA_256 run by persistent workgroups */ };
 int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                       int ldc, int flags, const float* bias, const float* res, int ldr, const void* aux_in, void* aux_out,
                       int ldaux, float* colsum, void* stream);
@@ -93,9 +94,10 @@ int mh_gemm_bf16_tile(int tile, int layout, int M, int N, int K, const void* A, 
  * vit_pytorch's Attention / FeedForward built at maestro/ssl/mae.py:135-174).  `grid` persistent four-wave workgroups (one per
  * CU: pass the CU count of the device, or of the stream's CU mask) split tiles x (K / 64) units evenly; a tile shared by
  * several workgroups is summed in workgroup order by the one that owns its last K step (deterministic, no atomics on C).
- *   tile   MH_TILE_SK_192 (192 x 128 x 64) or MH_TILE_SK_256 (256 x 128 x 64)
- *   flags  0 (bf16 C) or MH_GEMM_OUT_F32 | MH_GEMM_BIAS | MH_GEMM_RESIDUAL (fp32 C = A B + bias + res); K %% 64 == 0, K >= 128,
- *          N %% 128 == 0; anything else returns -2 (nothing launched, error string untouched): use mh_gemm_bf16
+ *   tile   MH_TILE_SK_DMA_256 (256 x 256 x 32, eight waves, LDS-DMA ring: gemm_sk_dma.hip; K %% 32 == 0, K >= 128, N %% 256 == 0) or the
+ *          four-wave register-staged MH_TILE_SK_192 (192 x 128 x 64) / MH_TILE_SK_256 (256 x 128 x 64) (K %% 64 == 0, N %% 128 == 0)
+ *   flags  0 (bf16 C) or MH_GEMM_OUT_F32 | MH_GEMM_BIAS | MH_GEMM_RESIDUAL (fp32 C = A B + bias + res); anything the tile does not
+ *          serve returns -2 (nothing launched, error string untouched): use mh_gemm_bf16
  *   workspace  mh_gemm_sk_workspace(tile, grid) bytes, 16-byte aligned, owned by the caller, ZEROED ONCE before its first use (the
  *          kernel leaves its flag words zero); launches that may run concurrently (different streams) need different workspaces.
  * Same fp32 sums per output element as mh_gemm_bf16 when no tile is shared; a shared tile adds its K ranges in ascending order. */

@@ -42,7 +42,7 @@ def _hipcc() -> str:
 
 def _digest(src: Path) -> str:
     h = hashlib.sha256()
-    for f in [src, CSRC / "common.hpp", CSRC / "gemm_common.hpp", CSRC / "gemm_ring.hpp", CSRC / "gemm_reg.hpp", ROOT / "include" / "maestro_hip.h"]:
+    for f in [src, CSRC / "common.hpp", CSRC / "gemm_common.hpp", CSRC / "gemm_ring.hpp", CSRC / "gemm_reg.hpp", CSRC / "gemm_sk_common.hpp", ROOT / "include" / "maestro_hip.h"]:
         h.update(f.read_bytes())
     h.update(" ".join(FLAGS + FILE_FLAGS.get(src.name, [])).encode())
     return h.hexdigest()[:16]

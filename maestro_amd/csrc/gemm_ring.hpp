@@ -50,8 +50,7 @@ __device__ __forceinline__ void piece_offsets(int ld, int rc0, int w, int l, int
 
 // fragment of rows/cols (rc0 + lane&15) of a stage's operand image: 8 bf16 along k = 8*(lane>>4) + j
 template <bool KMAJOR, int BX>
-__device__ __forceinline__ bf16x8 read_frag(const unsigned char* img, int rc0) {
-    const int l = threadIdx.x & 63;
+__device__ __forceinline__ bf16x8 read_frag(const unsigned char* img, int rc0, int l = threadIdx.x & 63) {
     if constexpr (!KMAJOR) {
         const int row = rc0 + (l & 15), g = l >> 4;
         return *reinterpret_cast<const bf16x8*>(img + row * 64 + ((g ^ kminor_sw(row)) << 4));

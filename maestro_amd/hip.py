@@ -62,7 +62,8 @@ _I, _F, _L = ctypes.c_int, ctypes.c_float, ctypes.c_long
 TILE_AUTO, TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128, TILE_DMA_128x4 = -1, 0, 1, 2, 3, 4, 5
 TILE_DMA_256_LOCKSTEP = 6   # MH_TILE_DMA_256 without the wave-group stagger (A/B experiments)
 TILE_REG_64, TILE_REG_192 = 13, 14   # the register-staged kernel with 64 x 128 / 192 x 128 tiles
-TILE_SK_192, TILE_SK_256 = 15, 16   # stream-K tiles (gemm_sk.hip): routed to mh_gemm_bf16_sk with a per-stream workspace
+TILE_SK_192, TILE_SK_256, TILE_SK_DMA_256 = 15, 16, 17   # stream-K tiles (gemm_sk.hip, gemm_sk_dma.hip): routed to mh_gemm_bf16_sk with a per-stream workspace
+SK_TILES = (TILE_SK_192, TILE_SK_256, TILE_SK_DMA_256)
 TILE_PP_128 = 7             # persistent 128x128 tile, epilogue of tile t inside the main loop of tile t + 1 (gemm_pp.hip)
 TILES = (TILE_REG_128, TILE_DMA_256, TILE_DMA_256x128, TILE_DMA_128x256, TILE_DMA_128, TILE_DMA_128x4)
 _LAYOUT_NAME = {0: "NT", 1: "NN", 2: "TN"}
@@ -71,7 +72,8 @@ _TILE_NAME = {TILE_REG_128: "gemm_kernel<{}>", TILE_DMA_256: "gemm_dma_kernel<25
               TILE_DMA_128: "gemm_dma_kernel<128x128,{}>", TILE_DMA_128x4: "gemm_dma_kernel<128x128q,{}>",
               TILE_DMA_256_LOCKSTEP: "gemm_dma_kernel<256x256,{}>", TILE_PP_128: "gemm_pp_kernel<{}>",
               TILE_REG_64: "gemm_kernel<{},64x128>", TILE_REG_192: "gemm_kernel<{},192x128>",
-              TILE_SK_192: "gemm_sk_kernel<{},192x128>", TILE_SK_256: "gemm_sk_kernel<{},256x128>"}
+              TILE_SK_192: "gemm_sk_kernel<{},192x128>", TILE_SK_256: "gemm_sk_kernel<{},256x128>",
+              TILE_SK_DMA_256: "gemm_sk_dma_kernel<256x256,{}>"}
 _tile_choice: dict = {}     # (layout, M, N, K, flags) -> fastest tile, filled while tuning is on
 _tuning = False
 
@@ -184,7 +186,7 @@ def gemm_sk(tile: int, layout: int, M: int, N: int, K: int, A, lda: int, B, ldb:
 
 
 def _gemm_tile(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr, aux_in, aux_out, ldaux, colsum) -> int:  # noqa: N803
-    if tile in (TILE_SK_192, TILE_SK_256):
+    if tile in SK_TILES:
         return gemm_sk(tile, layout, M, N, K, A, lda, B, ldb, C, ldc, flags, bias, res, ldr)
     return lib().mh_gemm_bf16_tile(_I(tile), _I(layout), _I(M), _I(N), _I(K), ptr(A), _I(lda), ptr(B), _I(ldb), ptr(C),
                                    _I(ldc), _I(flags), ptr(bias), ptr(res), _I(ldr), ptr(aux_in), ptr(aux_out), _I(ldaux),

@@ -300,13 +300,15 @@ def stress_raster(x: torch.Tensor, patch: int, g: torch.Generator) -> torch.Tens
     return x
 
 
-def make_batch(dataset, B: int, seed: int, stress: bool = False) -> dict:  # noqa: N803
-    """Synthetic batch of the wire format: rasters fp32 [B,D,C,S,S], dates int16 [B,D,3]."""
+def make_batch(dataset, B: int, seed: int, stress: bool = False, sizes: dict | None = None) -> dict:  # noqa: N803
+    """Synthetic batch of the wire format: rasters fp32 [B,D,C,S,S], dates int16 [B,D,3].  ``sizes``: modality ->
+    raster edge when the data does NOT arrive at ``image_size`` (resize_and_rescale then interpolates, mim.py:425-437)."""
     batch = {}
     for i, (m, c) in enumerate(dataset.inputs.items()):
         g = torch.Generator().manual_seed(1234 + 97 * seed + i)
         C = c.bands if isinstance(c.bands, int) else sum(len(b) for b in c.bands)  # noqa: N806
-        batch[m] = torch.rand(B, c.num_dates, C, c.image_size, c.image_size, generator=g)
+        S = (sizes or {}).get(m, c.image_size)  # noqa: N806
+        batch[m] = torch.rand(B, c.num_dates, C, S, S, generator=g)
         if stress:
             batch[m] = stress_raster(batch[m], c.patch_size.mae, g)
         d = torch.arange(c.num_dates)
@@ -371,6 +373,29 @@ def tie_case_table():
     }
 
 
+def resize_case_table():
+    """Cases whose rasters do NOT arrive at ``image_size`` (round 6): the non-identity branch of
+    ``resize_and_rescale`` (mim.py:425-437) with the interpolation modes the reference's own tests sweep (tests/test_model.py:8-132),
+    a ``dem`` modality included so that ``rescale_elev`` follows the resize; the resized, rescaled raster (the returned batch = the
+    loss target) is stored for every modality."""
+    return {
+        # aerial arrives larger (80 -> 64: down-sampling), dem smaller (48 -> 64: up-sampling, then 30 (ch0 - ch1))
+        "rs_bilinear_aerial_dem": dict(
+            dataset="flair", ds_kwargs=dict(filter_inputs=["aerial", "dem"], filter_targets=[]),
+            mods=dict(aerial=dict(image_size=64, patch=16, bands=4, norm_bands=[1, 3], norm_fac=255.0),
+                      dem=dict(image_size=64, patch=32, bands=2, norm_fac=1000.0, rescale_elev=True)),
+            size="tiny", model_kw=dict(depth=3), inter_depth=1, fusion="group", B=2, seed=83,
+            interpolate="bilinear", raster_size=dict(aerial=80, dem=48)),
+        # bicubic (overshoots: values leave [0, 1]); aerial up-sampled 40 -> 64, dem down-sampled 96 -> 64, s2 at its native size
+        "rs_bicubic_aerial_dem_s2": dict(
+            dataset="flair", ds_kwargs=dict(filter_inputs=["aerial", "dem", "s2"], filter_targets=[]),
+            mods=dict(aerial=dict(image_size=64, patch=16, bands=4, norm_bands=[1, 3], norm_fac=255.0),
+                      dem=dict(image_size=64, patch=32, bands=2, norm_fac=1000.0, rescale_elev=True)),
+            size="tiny", model_kw=dict(depth=3), inter_depth=1, fusion="group", B=2, seed=89,
+            interpolate="bicubic", raster_size=dict(aerial=40, dem=96)),
+    }
+
+
 def _tie_free(noise: torch.Tensor, struct: torch.Tensor, k: int) -> bool:
     return bool((struct.reshape(noise.shape).sum(dim=1) <= k).all())
 
@@ -391,10 +416,11 @@ def run_case(name: str, case: dict, ref, ours) -> dict:
     mask_ref, mask_our = ref.MaskConfig(**case.get("mask_kw", {})), ours.MaskConfig(**case.get("mask_kw", {}))
 
     torch.manual_seed(1000 + case["seed"])
-    ssl = ref.model.SSLModule(datasets=ds_ref, mask=mask_ref, interpolate="nearest", fusion_mode=case["fusion"],
+    interp = case.get("interpolate", "nearest")
+    ssl = ref.model.SSLModule(datasets=ds_ref, mask=mask_ref, interpolate=interp, fusion_mode=case["fusion"],
                               inter_depth=case["inter_depth"], model="mae", model_size=case["size"],
                               loss="l2_norm", use_ema=False)
-    common = dict(interpolate="nearest", fusion_mode=case["fusion"], inter_depth=case["inter_depth"], model="mae",
+    common = dict(interpolate=interp, fusion_mode=case["fusion"], inter_depth=case["inter_depth"], model="mae",
                   num_levels=1, type_head="attentive", fac_abs_enc=1.0, fac_date_enc=1.0)
     ssl.model = getattr(ref.mae, f"mae_{case['size']}")(datasets=ds_ref, mask=mask_ref, **common, **case["model_kw"])
     oracle = omae.build_oracle(ds_our, mask_our, model_size=case["size"], **common, **case["model_kw"])
@@ -404,7 +430,7 @@ def run_case(name: str, case: dict, ref, ours) -> dict:
     assert all(k.startswith("heads.") for k in missing), missing
     ssl.trainer = SimpleNamespace(ssl_phase="pretrain")
 
-    batch = make_batch(ds_our.dataset, case["B"], case["seed"], stress=case.get("stress", False))
+    batch = make_batch(ds_our.dataset, case["B"], case["seed"], stress=case.get("stress", False), sizes=case.get("raster_size"))
     out = {"weights_checksum": np.float64(chk)}
 
     # ---- reference forward/backward with recorded RNG draws
@@ -457,8 +483,9 @@ def run_case(name: str, case: dict, ref, ours) -> dict:
         out[f"pixels_rec/{m}"] = rec[m].detach().numpy().astype(np.float32)
         # reference's token-level mask (pixel mask is its repeat): take the top-left pixel of each patch, channel 0
         out[f"mask_tok/{m}"] = np.packbits(token_masks(msk[m], ds_our.dataset.inputs[m]).numpy(), axis=2)
-        out[f"target/{m}"] = rb[m].detach().numpy().astype(np.float32) if ds_our.dataset.inputs[m].rescale_elev \
-            else np.zeros(0, np.float32)
+        # the returned batch (= the loss target) where the reference changed it: elevation rescale and / or a real resize
+        out[f"target/{m}"] = rb[m].detach().numpy().astype(np.float32) \
+            if (ds_our.dataset.inputs[m].rescale_elev or m in case.get("raster_size", {})) else np.zeros(0, np.float32)
 
     # ---- report oracle-vs-reference agreement now (the tests re-check from the stored vectors)
     report = {}
@@ -686,7 +713,7 @@ def main() -> None:
     only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None   # optional: comma-separated case names
     if which in ("all", "pretrain"):
         np.savez_compressed(GOLDEN / "layers.npz", **layer_vectors(ref))
-        for name, case in {**case_table(), **tie_case_table()}.items():
+        for name, case in {**case_table(), **tie_case_table(), **resize_case_table()}.items():
             if only is not None and name not in only:
                 continue
             out = run_case(name, case, ref, ours)

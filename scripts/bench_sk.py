@@ -21,7 +21,9 @@ SHAPES = [("fc2", 0, 8192, 768, 3072, F32), ("dfc1", 1, 8192, 768, 3072, 0), ("d
           ("jnt fc2", 0, 11392, 768, 3072, F32), ("jnt dfc1", 1, 11392, 768, 3072, 0),
           ("dec fc2", 0, 32768, 512, 3072, F32), ("dec dfc1", 1, 32768, 512, 3072, 0), ("dec dqkv", 1, 32768, 512, 1536, 0),
           ("ds2 fc2", 0, 12800, 512, 3072, F32), ("ds2 dfc1", 1, 12800, 512, 3072, 0)]
-TILES = [("auto", None), ("sk192", hip.TILE_SK_192), ("sk256", hip.TILE_SK_256)]
+TILES = [("auto", None), ("skd256", hip.TILE_SK_DMA_256), ("sk192", hip.TILE_SK_192), ("sk256", hip.TILE_SK_256)]
+if "--dma-only" in sys.argv:
+    TILES = TILES[:2]
 only = [a for a in sys.argv[1:] if not a.startswith("-")]
 throughput = "--no-throughput" not in sys.argv
 

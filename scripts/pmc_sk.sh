@@ -7,7 +7,8 @@ out=$R/gpurun_out/pmc_sk
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 LAY=${LAY:-0}
-for v in ${VARIANTS:-"reg128:tile0 reg192:tile14 sk192:tile15 sk256:tile16"}; do
+VARIANTS=${VARIANTS:-reg128:tile0 reg192:tile14 sk192:tile15 sk256:tile16}
+for v in $VARIANTS; do
   name=${v%%:*}; impl=${v##*:}
   i=0
   for ctrs in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL"; do

@@ -41,15 +41,18 @@ SHAPES = [
     (2048, 512, 1536),
     (40, 128, 192),       # M smaller than a wave tile
 ]
+TILES = [15, 16, 17]      # MH_TILE_SK_192, MH_TILE_SK_256 (four waves, register-staged), MH_TILE_SK_DMA_256 (eight waves, LDS-DMA ring)
 
 
-@pytest.mark.parametrize("tile", [15, 16])
+@pytest.mark.parametrize("tile", TILES)
 @pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_sk_exact_integers(tile, layout, shape):
     from maestro_amd import hip
     dev = _dev()
     M, N, K = shape
+    if tile == 17:        # 256-wide output tiles
+        N = (N + 255) // 256 * 256
     A, B, want = _operands(layout, M, N, K, dev)
     g = torch.Generator().manual_seed(5)
     bias = torch.randint(-4, 5, (N,), generator=g).float().to(dev)
@@ -71,7 +74,7 @@ def test_sk_exact_integers(tile, layout, shape):
         assert int(ws[:4092].view(torch.int32).abs().sum().item()) == 0, "flag words must be zero between launches"
 
 
-@pytest.mark.parametrize("tile", [15, 16])
+@pytest.mark.parametrize("tile", TILES)
 def test_sk_matches_the_library_rule_on_random_data(tile):
     """Random data: the stream-K result equals mh_gemm_bf16's up to the order in which a shared tile's K ranges are added."""
     from maestro_amd import hip
@@ -96,7 +99,8 @@ def test_sk_matches_the_library_rule_on_random_data(tile):
         assert torch.equal(C1, C2)
 
 
-def test_sk_through_the_tile_table_and_graph_replay():
+@pytest.mark.parametrize("tile", [15, 17])
+def test_sk_through_the_tile_table_and_graph_replay(tile):
     """hip.gemm(tile=TILE_SK_*) routes to the stream-K entry; a captured launch replays with the same result."""
     from maestro_amd import hip
     dev = _dev()
@@ -105,13 +109,13 @@ def test_sk_through_the_tile_table_and_graph_replay():
     C = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
-        hip.gemm(0, M, N, K, A, K, B, K, C, N, 0, tile=hip.TILE_SK_192)        # eager first: allocates the stream's workspace
+        hip.gemm(0, M, N, K, A, K, B, K, C, N, 0, tile=tile)        # eager first: allocates the stream's workspace
         s.synchronize()
         assert torch.equal(C, want.bfloat16())
         C.zero_()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=s):
-            hip.gemm(0, M, N, K, A, K, B, K, C, N, 0, tile=hip.TILE_SK_192)
+            hip.gemm(0, M, N, K, A, K, B, K, C, N, 0, tile=tile)
         for _ in range(3):
             C.zero_()
             graph.replay()
@@ -128,3 +132,4 @@ def test_sk_declines_what_it_does_not_serve():
     assert hip.gemm_sk(15, 0, 256, 256, 256, A, 256, A, 256, C, 256, hip.BIAS, bias=bias) == -2      # epilogue not served
     assert hip.gemm_sk(15, 0, 256, 200, 256, A, 256, A, 256, C, 256, 0) == -2                       # N % 128
     assert hip.gemm_sk(15, 0, 256, 256, 96, A, 256, A, 256, C, 256, 0) == -2                        # K % 64
+    assert hip.gemm_sk(17, 0, 256, 128, 256, A, 256, A, 256, C, 256, 0) == -2                       # the 256-wide tile: N % 256

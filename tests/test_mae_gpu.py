@@ -17,11 +17,12 @@ import torch
 import maestro_amd.conf as conf
 from maestro_amd.ssl import mae as pmae
 from oracle import mae as om
-from oracle.gen_golden import build_datasets, case_table, init_weights, make_batch, tie_case_table, token_masks
+from oracle.gen_golden import build_datasets, case_table, init_weights, make_batch, resize_case_table, tie_case_table, token_masks
 
 pytestmark = pytest.mark.gpu
 CASES = case_table()
 TIE_CASES = tie_case_table()
+RESIZE_CASES = resize_case_table()
 LOSS_TOL, PIX_TOL, GRAD_TOL = 2.1e-3, 1e-2, 3e-2
 COMMON = dict(interpolate="nearest", model="mae", num_levels=1, type_head="attentive", fac_abs_enc=1.0, fac_date_enc=1.0)
 
@@ -34,16 +35,17 @@ def _setup(name, golden_dir, table=None):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     dev = torch.device("cuda:0")
-    case = (table or CASES)[name]
+    case = (table or {**CASES, **RESIZE_CASES})[name]
     gold = np.load(golden_dir / f"{name}.npz", allow_pickle=False)
     ds = build_datasets(case, conf)
-    kw = dict(fusion_mode=case["fusion"], inter_depth=case["inter_depth"], **COMMON, **case["model_kw"])
+    kw = dict(fusion_mode=case["fusion"], inter_depth=case["inter_depth"], **{**COMMON, "interpolate": case.get("interpolate", "nearest")},
+              **case["model_kw"])
     mask_cfg = conf.MaskConfig(**case.get("mask_kw", {}))
     oracle = om.build_oracle(ds, mask_cfg, model_size=case["size"], **kw)
     init_weights(oracle, case["seed"])
     model = getattr(pmae, f"mae_{case['size']}")(datasets=ds, mask=mask_cfg, **kw)
     missing, unexpected = model.load_state_dict(oracle.state_dict(), strict=True)
-    batch = make_batch(ds.dataset, case["B"], case["seed"], stress=case.get("stress", False))
+    batch = make_batch(ds.dataset, case["B"], case["seed"], stress=case.get("stress", False), sizes=case.get("raster_size"))
     noise, struct = {}, {}
     for key in gold.files:
         if key.startswith("noise/"):
@@ -119,6 +121,26 @@ def _check_case(golden_dir, name, wgrad, observed, tag):
         assert ok, f"{k}: grad rel err {err / max(ref, 1e-12):.3e} (|ref|={ref:.3e})"
     observed(tag, f"grad_worst/{worst[1]}", worst[0])
     print(f"[{name}] loss hip={loss.item():.6f} oracle={oloss.item():.6f} worst grad rel err {worst}")
+
+
+@pytest.mark.parametrize("name", list(RESIZE_CASES))
+def test_resized_inputs_match_the_reference(golden_dir, name, observed):
+    """Round 6: rasters that do NOT arrive at ``image_size`` go through ``mh_resize`` (bilinear / bicubic,
+    PyTorch's align_corners=False maps) and, for ``dem``, the elevation rescale AFTER the resize -- against goldens generated by the
+    reference's own ``resize_and_rescale`` (mim.py:425-437): masks bit-exact, reconstructions, loss, every gradient (``_check_case``),
+    and the returned batch (the loss target) against the reference's resized rasters."""
+    _check_case(golden_dir, name, "deferred", observed, f"tiny_resize/{name}")
+    dev, case, gold, ds, oracle, model, batch, noise, struct = _setup(name, golden_dir)
+    eng = model.engine(case["B"], dev, loss="l2_norm")
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    eng.forward(dbatch, noise=noise, struct=struct)
+    returned = eng.returned_batch(dbatch)
+    for m in case["raster_size"]:
+        want = torch.from_numpy(gold[f"target/{m}"])
+        assert returned[m].shape == want.shape and want.shape[-1] == ds.dataset.inputs[m].image_size
+        err = (returned[m].cpu() - want).abs().max().item()
+        observed(f"tiny_resize/{name}", f"target/{m}", err)
+        assert err < 2e-5 * max(1.0, want.abs().max().item()), (m, err)
 
 
 @pytest.mark.parametrize("name", list(TIE_CASES))

@@ -12,10 +12,11 @@ import torch
 import maestro_amd.conf as conf
 from oracle import layers as ol
 from oracle import mae as om
-from oracle.gen_golden import build_datasets, case_table, init_weights, make_batch, tie_case_table, token_masks
+from oracle.gen_golden import build_datasets, case_table, init_weights, make_batch, resize_case_table, tie_case_table, token_masks
 
 CASES = case_table()
 TIE_CASES = tie_case_table()
+RESIZE_CASES = resize_case_table()     # rasters that do not arrive at image_size: bilinear / bicubic resize_and_rescale (mim.py:425-437)
 COMMON = dict(interpolate="nearest", model="mae", num_levels=1, type_head="attentive", fac_abs_enc=1.0,
               fac_date_enc=1.0)
 
@@ -25,10 +26,11 @@ def _load(golden_dir, name):
 
 
 def build_case(name, table=None):
-    case = (table or CASES)[name]
+    case = (table or {**CASES, **RESIZE_CASES})[name]
     ds = build_datasets(case, conf)
     oracle = om.build_oracle(ds, conf.MaskConfig(**case.get("mask_kw", {})), model_size=case["size"], fusion_mode=case["fusion"],
-                             inter_depth=case["inter_depth"], **COMMON, **case["model_kw"])
+                             inter_depth=case["inter_depth"], **{**COMMON, "interpolate": case.get("interpolate", "nearest")},
+                             **case["model_kw"])
     chk = init_weights(oracle, case["seed"])
     return case, ds, oracle, chk
 
@@ -68,12 +70,14 @@ def test_layer_vectors(golden_dir):
     assert np.array_equal(mimg.numpy(), g["pixelify_mask_out"])
 
 
-@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("name", list(CASES) + list(RESIZE_CASES))
 def test_forward_loss_grads_match_reference(golden_dir, name):
     gold = _load(golden_dir, name)
     case, ds, oracle, chk = build_case(name)
     assert abs(chk - float(gold["weights_checksum"])) < 1e-6 * chk, "seeded weights differ from golden run"
-    batch = make_batch(ds.dataset, case["B"], case["seed"], stress=case.get("stress", False))
+    batch = make_batch(ds.dataset, case["B"], case["seed"], stress=case.get("stress", False), sizes=case.get("raster_size"))
+    if name in RESIZE_CASES:       # the reference's resized (and rescaled) rasters are stored for every modality that was resized
+        assert all(gold[f"target/{m}"].shape[-1] == ds.dataset.inputs[m].image_size != batch[m].shape[-1] for m in case["raster_size"])
     noise, struct = injected_rng(gold, oracle)
     tie_free = {k.split("/", 1)[1]: bool(gold[k]) for k in gold.files if k.startswith("tie_free/")}
     assert all(tie_free.values()), "golden cases are chosen tie-free for mask selection"
@@ -100,7 +104,7 @@ def test_forward_loss_grads_match_reference(golden_dir, name):
         if group_of[m] not in multi_mod_groups:
             np.testing.assert_allclose(rec[m].detach().numpy(), gold[f"pixels_rec/{m}"], atol=5e-5)
         if gold[f"target/{m}"].size:
-            np.testing.assert_allclose(b[m].numpy(), gold[f"target/{m}"], atol=1e-6)  # rescale_elev target
+            np.testing.assert_allclose(b[m].numpy(), gold[f"target/{m}"], atol=2e-6)  # rescale_elev / resized target
 
     # 2) reference tie order reproduced -> everything matches (tie order is the sole divergence)
     b, rec, msk, _ = run(bool(multi_mod_groups))
