@@ -507,12 +507,54 @@ class EngineBase:
             self._ready_spans.append(self.store.span(ps))
 
     # ------------------------------------------------------------------------------------------ streams / graphs
+    def _masked_streams(self, n: int):
+        """MAESTRO_CU_MASK="6,2" (experiment): group i runs on a stream restricted to its own XCDs (here XCDs 0-5
+        and 6-7) -- streams made by hipExtStreamCreateWithCUMask (bit i of the mask = CU i; the driver deals mask bits round-robin
+        over the XCCs, so XCD x owns the bits i with i % 8 == x) and wrapped as torch ExternalStreams.  None when unset / not n parts."""
+        spec = os.environ.get("MAESTRO_CU_MASK")
+        if not spec:
+            return None
+        cached = getattr(self, "_cu_streams", None)
+        if cached is not None and len(cached) == n:
+            return cached
+        parts = [int(x) for x in spec.split(",")]
+        if len(parts) != n or sum(parts) != 8:
+            return None
+        import ctypes
+        rt = ctypes.CDLL("libamdhip64.so")
+        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        streams, x0 = [], 0
+        for cnt in parts:
+            xcds = set(range(x0, x0 + cnt))
+            x0 += cnt
+            words = [0] * ((ncu + 31) // 32)
+            for i in range(ncu):
+                if i % 8 in xcds:
+                    words[i // 32] |= 1 << (i % 32)
+            arr = (ctypes.c_uint32 * len(words))(*words)
+            h = ctypes.c_void_p()
+            rc = rt.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(len(words)), arr)
+            if rc != 0:
+                raise hip.HipExtensionError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+            streams.append(torch.cuda.ExternalStream(h.value, device=self.device))
+        self._cu_streams = streams
+        return streams
+
     def _run_parallel(self, fns) -> None:
         if len(fns) == 1 or not self.multi_stream or not self.group_streams:
             for fn in fns:
                 fn()
             return
         main = torch.cuda.current_stream()
+        masked = self._masked_streams(len(fns))
+        if masked is not None:      # every group on its own XCD partition (the main stream only forks and joins)
+            for st, fn in zip(masked, fns):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    fn()
+            for st in masked:
+                main.wait_stream(st)
+            return
         sides = self.side_streams[: len(fns) - 1]
         for side in sides:
             side.wait_stream(main)
@@ -1193,9 +1235,16 @@ class MAEEngine(EngineBase):
                 cur = off + n
             if cur < self.store.total:
                 spans.append((cur, self.store.total - cur))
+            # the patch-embed weight-gradient staging buffers ([E, Kpad] fp32 per modality: split-K atomics accumulate into them) are
+            # cleared by the same launch -- offsets relative to the gradient buffer's base (one flat device address space) -- instead
+            # of one torch fill each inside the backward
+            for b in self.mb.values():
+                if b.get("dw_conv") is not None:
+                    spans.append(((b["dw_conv"].data_ptr() - base) // 4, b["dw_conv"].numel()))
             dev = torch.tensor([v for sp in spans for v in sp], dtype=torch.int64, device=self.device)
             z = self._zero_lists[plan] = (dev, len(spans), max(n for _, n in spans))
         hip.zero_spans(self.store.grad, z[0], z[1], z[2])
+        self._dw_conv_clear = True       # consumed by the next backward (a backward without a zero_grad before it clears them itself)
 
     # Minimum number of 256x256 output tiles for which one grouped wgrad launch beats the per-GEMM split-K launches
     # (measured on C3: 1944 tiles 3.10 -> 1.47 ms, 384 tiles 1.83 -> 1.17 ms, 324 tiles 0.79 -> 0.57 ms; 256 CUs).
@@ -1298,6 +1347,8 @@ class MAEEngine(EngineBase):
         key = getattr(self, "_cur_key", None)
         plan = self._plan = self._wgrad_plan()
         sfx = f":{plan}:{'h' if self.grad_hook is not None else 'n'}"   # graphs are specific to the launch plan
+        if not getattr(self, "_dw_conv_clear", False):
+            sfx += ":nz"     # no zero_grad since the last backward: this launch list clears the conv-gradient staging buffers itself
         if self.fp8 is not None and self.fp8.dgrad:
             sfx += ":f8" if self.fp8.grad_ready else ":cal"       # (the first backward calibrates the gradient scales in bf16)
         cuts = self._enc_cuts()
@@ -1314,6 +1365,7 @@ class MAEEngine(EngineBase):
                 if plan == "ovl":
                     fn = self._with_overlapped_wgrads(fn, segs[i - 1][2] if i else None, items if i == len(segs) - 1 else None)
                 self._segment(name + sfx, key, fn)
+        self._dw_conv_clear = False
         if self.fp8 is not None:
             self.fp8.end_of_backward()      # next step's e5m2 gradient scales from this backward's absmax values
 
@@ -1421,7 +1473,8 @@ class MAEEngine(EngineBase):
                 hip.embed_finish_bwd(gbuf["dxg"], b["yconv"], b["gn_stats"], pe.norm.weight, b["dyc"],
                                      ps.g(pe.norm.weight), ps.g(pe.norm.bias), b["gn_sums"], s.Beff, s.D, s.L, E,
                                      s.tok_off, g.L)
-                b["dw_conv"].zero_()
+                if not getattr(self, "_dw_conv_clear", False):   # (normally cleared by zero_grad's span launch)
+                    b["dw_conv"].zero_()
                 hip.gemm(hip.GEMM_TN, E, s.Kpad, T, b["dyc"], E, b["cols"], s.Kpad, b["dw_conv"], s.Kpad, AT)
                 hip.unpack_rows_add(b["dw_conv"], ps.g(pe.conv.weight), E, s.K, s.Kpad)
                 hip.colsum(b["dyc"], ps.g(pe.conv.bias), T, E, E)
