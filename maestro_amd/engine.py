@@ -507,54 +507,14 @@ class EngineBase:
             self._ready_spans.append(self.store.span(ps))
 
     # ------------------------------------------------------------------------------------------ streams / graphs
-    def _masked_streams(self, n: int):
-        """MAESTRO_CU_MASK="6,2" (experiment): group i runs on a stream restricted to its own XCDs (here XCDs 0-5
-        and 6-7) -- streams made by hipExtStreamCreateWithCUMask (bit i of the mask = CU i; the driver deals mask bits round-robin
-        over the XCCs, so XCD x owns the bits i with i % 8 == x) and wrapped as torch ExternalStreams.  None when unset / not n parts."""
-        spec = os.environ.get("MAESTRO_CU_MASK")
-        if not spec:
-            return None
-        cached = getattr(self, "_cu_streams", None)
-        if cached is not None and len(cached) == n:
-            return cached
-        parts = [int(x) for x in spec.split(",")]
-        if len(parts) != n or sum(parts) != 8:
-            return None
-        import ctypes
-        rt = ctypes.CDLL("libamdhip64.so")
-        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
-        streams, x0 = [], 0
-        for cnt in parts:
-            xcds = set(range(x0, x0 + cnt))
-            x0 += cnt
-            words = [0] * ((ncu + 31) // 32)
-            for i in range(ncu):
-                if i % 8 in xcds:
-                    words[i // 32] |= 1 << (i % 32)
-            arr = (ctypes.c_uint32 * len(words))(*words)
-            h = ctypes.c_void_p()
-            rc = rt.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(len(words)), arr)
-            if rc != 0:
-                raise hip.HipExtensionError(f"hipExtStreamCreateWithCUMask failed ({rc})")
-            streams.append(torch.cuda.ExternalStream(h.value, device=self.device))
-        self._cu_streams = streams
-        return streams
-
     def _run_parallel(self, fns) -> None:
         if len(fns) == 1 or not self.multi_stream or not self.group_streams:
             for fn in fns:
                 fn()
             return
+        # (round 6: XCD-partitioned group streams -- hipExtStreamCreateWithCUMask, one partition per group -- were tried and dropped:
+        #  the pool's boxes do not honour the mask, profiles/r06_experiments.md #6)
         main = torch.cuda.current_stream()
-        masked = self._masked_streams(len(fns))
-        if masked is not None:      # every group on its own XCD partition (the main stream only forks and joins)
-            for st, fn in zip(masked, fns):
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    fn()
-            for st in masked:
-                main.wait_stream(st)
-            return
         sides = self.side_streams[: len(fns) - 1]
         for side in sides:
             side.wait_stream(main)
@@ -1218,6 +1178,10 @@ class MAEEngine(EngineBase):
         plan = self._wgrad_plan()
         if plan == "fused":
             self.store.grad.zero_()
+            for b in self.mb.values():
+                if b.get("dw_conv") is not None:
+                    b["dw_conv"].zero_()
+            self._dw_conv_clear = True
             return
         z = self._zero_lists.get(plan)
         if z is None:

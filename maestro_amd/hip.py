@@ -32,6 +32,10 @@ def lib() -> ctypes.CDLL:
             raise HipExtensionError(
                 f"{_LIB_PATH} not found: build it with `python -m maestro_amd.csrc.build` "
                 "(or __graft_entry__.build()).  The MAE hot path has no fallback implementation.")
+        retired = [v for v in ("MAESTRO_GROUPED", "MH_GEMM_SPLITK", "MH_ATTN_BWD", "MAESTRO_CU_MASK") if os.environ.get(v)]
+        if retired:     # their kernels / code paths were removed (rounds 5-6): refuse instead of silently running the default path
+            raise HipExtensionError(f"{', '.join(retired)}: retired experiment switch(es) -- the variant no longer exists, this run "
+                                    "would measure the default path (INTEGRATION.md, profiles/r05_experiments.md, r06_experiments.md)")
         _lib = ctypes.CDLL(str(_LIB_PATH))
         _lib.mh_last_error.restype = ctypes.c_char_p
     return _lib

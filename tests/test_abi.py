@@ -75,3 +75,18 @@ def test_library_reads_no_environment():
     switches (MH_GEMM_TILE, MH_GEMM_DMA, MH_DMA_STAGGER, MH_FP8_TILE) are parsed on the host side (maestro_amd/hip.py)."""
     for src in list((ROOT / "maestro_amd" / "csrc").glob("*.hip")) + list((ROOT / "maestro_amd" / "csrc").glob("*.hpp")):
         assert "getenv" not in src.read_text(), f"{src.name} reads the environment"
+
+
+def test_retired_experiment_switches_are_refused(monkeypatch):
+    """Round 6: MAESTRO_GROUPED / MH_GEMM_SPLITK / MH_ATTN_BWD / MAESTRO_CU_MASK selected code that no longer exists; a run
+    that sets one must fail loudly instead of measuring the default path under the variant's name."""
+    import pytest
+
+    from maestro_amd import hip
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setenv("MH_GEMM_SPLITK", "1")
+    with pytest.raises(hip.HipExtensionError, match="retired"):
+        hip.lib()
+    monkeypatch.delenv("MH_GEMM_SPLITK")
+    monkeypatch.setattr(hip, "_lib", None)
+    assert hip.lib() is not None
