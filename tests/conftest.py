@@ -38,6 +38,21 @@ def pytest_collection_modifyitems(session, config, items):
     items.sort(key=rank)          # stable: the order inside a file is kept
 
 
+def pytest_runtest_logreport(report):
+    """One line per finished GPU test under ``gpurun_out/`` (scratch, merged back from the GPU box): the suite has stretches of
+    several minutes (two-rank and child-process tests) that print nothing, and a run that writes nothing for seven minutes is
+    taken to be hung by the GPU runner."""
+    if report.when != "call" or "gpu" not in getattr(report, "keywords", {}):
+        return
+    try:
+        out = ROOT / "gpurun_out"
+        out.mkdir(exist_ok=True)
+        with open(out / "gputest_progress.log", "a") as f:
+            f.write(f"{report.outcome:7s} {report.duration:7.2f}s {report.nodeid}\n")
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
