@@ -175,17 +175,6 @@ int mh_layernorm_fwd(const float* x, int x_L, int x_off, const float* gamma, con
                      int y_off, int y_is_f32, float* mean, float* rstd, int B, int n, int dim, float eps, void* stream);
 /* The same with a second output for the fp8 path: y8 = OCP e4m3 of (y * *y8_scale) in y's row map (the A operand of the next
  * mh_gemm_fp8), max |y| folded into the amax row y8_amax (optional; delayed scaling).  y is bf16 (the backward's wgrad reads it). */
-/* mh_layernorm_fwd / mh_layernorm_bwd_partial that also PREFETCH `prefetch_bytes` bytes at `prefetch` (read-only, 4-byte aligned; null:
- * none) into the caches: wave 0 of every workgroup touches one dword per 128-byte line of its share.  Meant for the weights of the GEMMs
- * that follow this LayerNorm in the layer (vit_pytorch Attention / FeedForward: to_qkv + to_out, net.1 + net.4, contiguous in a flat
- * weight buffer): a layer's weights are read once per pass and would otherwise be fetched from HBM under the GEMM's first tiles.
- * Only the straight-line kernels (dim = 256 k, bf16 y / dy) prefetch; the generic ones ignore the range.  Outputs are unaffected. */
-int mh_layernorm_fwd_pf(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y, int y_L, int y_off,
-                        int y_is_f32, float* mean, float* rstd, int B, int n, int dim, float eps, const void* prefetch,
-                        long prefetch_bytes, void* stream);
-int mh_layernorm_bwd_partial_pf(const void* dy, int dy_L, int dy_off, int dy_is_f32, const float* x, int x_L, int x_off,
-                                const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx, void* dx_bf16,
-                                float* workspace, int B, int n, int dim, const void* prefetch, long prefetch_bytes, void* stream);
 int mh_layernorm_fwd_fp8(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y, int y_L,
                          int y_off, float* mean, float* rstd, int B, int n, int dim, float eps, void* y8,
                          const float* y8_scale, float* y8_amax, void* stream);

@@ -105,20 +105,6 @@ __device__ __forceinline__ float ln_wave_sum(float v) {
     return wave_sum(v);
 #endif
 }
-// Weight prefetch (round 6; mh_layernorm_fwd_pf / mh_layernorm_bwd_partial_pf).  A layer's weights (4.7-9.4 MB of the 352 MB bf16
-// shadow, read once per forward and once per backward) come from HBM when the GEMM behind this LayerNorm starts: every workgroup of
-// that launch then waits ~2 us for its first weight tile, and again at every tile transition.  Wave 0 of a workgroup touches ONE
-// dword in each of 64 consecutive 128-byte lines (8 KiB per wave instruction, one register, result discarded): the lines are in the
-// Infinity Cache (and one XCD's L2) by the time the GEMM asks for them.  ~0.1 us of one wave per workgroup; 12 % more bytes on
-// this HBM-bound launch.
-__device__ __forceinline__ void prefetch_lines(const void* pf, long pf_bytes) {
-    const int lane = threadIdx.x & 63;
-    for (long off = (long)blockIdx.x * 8192; off < pf_bytes; off += (long)gridDim.x * 8192) {
-        const long a = off + lane * 128;
-        if (a < pf_bytes) (void)*reinterpret_cast<const volatile uint32_t*>(reinterpret_cast<const char*>(pf) + a);
-    }
-}
-
 // FP8 = true (mh_layernorm_fwd_fp8): the same kernel also writes the e4m3 copy of the output (the next GEMM's A operand) and
 // folds |y| into the tensor's amax row; the bf16 output is the SAME instruction sequence, hence bit-identical to FP8 = false.
 template <int NV, bool FP8>
@@ -126,11 +112,10 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const float* __restric
                                                           const float* __restrict__ beta, bf16_t* __restrict__ y, RowMap ym,
                                                           float* __restrict__ mean, float* __restrict__ rstd, int B, int n,
                                                           float eps, uint8_t* __restrict__ y8, const float* __restrict__ y8_scale,
-                                                          float* __restrict__ y8_amax, const void* __restrict__ pf, long pf_bytes) {
+                                                          float* __restrict__ y8_amax) {
     constexpr int dim = 256 * NV;
     const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (pf && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) prefetch_lines(pf, pf_bytes);
     if (row >= B * n) return;
     const int b = row / n, j = row - b * n;
     const float* xr = x + map_row(xm, b, j) * dim;
@@ -318,13 +303,11 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const bf16_t* __restri
                                                           RowMap xm, const float* __restrict__ gamma,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ dres, float* __restrict__ dx,
-                                                          bf16_t* __restrict__ dx_bf16, float* __restrict__ partial, int B, int n,
-                                                          const void* __restrict__ pf, long pf_bytes) {
+                                                          bf16_t* __restrict__ dx_bf16, float* __restrict__ partial, int B, int n) {
     constexpr int dim = 256 * NV;
     static_assert(DEPTH >= 1 && DEPTH <= ROWS_PER_WAVE, "prefetch distance in rows");
     extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][3][dim]
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (pf && w == 0) prefetch_lines(pf, pf_bytes);
     f32x4 gsum[NV], bsum[NV], csum[NV], gm[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -452,21 +435,13 @@ static int ln_nv(int dim) { const int v = (dim / 4 + 63) / 64; return v <= 4 ? v
 
 static int layernorm_fwd_impl(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y, int y_L,
                               int y_off, int y_is_f32, float* mean, float* rstd, int B, int n, int dim, float eps, void* y8,
-                              const float* y8_scale, float* y8_amax, void* stream, const void* pf = nullptr, long pf_bytes = 0);
+                              const float* y8_scale, float* y8_amax, void* stream);
 
 extern "C" int mh_layernorm_fwd(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y,
                                 int y_L, int y_off, int y_is_f32, float* mean, float* rstd, int B, int n, int dim,
                                 float eps, void* stream) {
     return layernorm_fwd_impl(x, x_L, x_off, gamma, beta, y, y_L, y_off, y_is_f32, mean, rstd, B, n, dim, eps, nullptr, nullptr,
                               nullptr, stream);
-}
-
-extern "C" int mh_layernorm_fwd_pf(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y,
-                                   int y_L, int y_off, int y_is_f32, float* mean, float* rstd, int B, int n, int dim,
-                                   float eps, const void* prefetch, long prefetch_bytes, void* stream) {
-    MH_CHECK_ARG(!prefetch || ((uintptr_t)prefetch % 4 == 0 && prefetch_bytes >= 0), "mh_layernorm_fwd_pf: prefetch range");
-    return layernorm_fwd_impl(x, x_L, x_off, gamma, beta, y, y_L, y_off, y_is_f32, mean, rstd, B, n, dim, eps, nullptr, nullptr,
-                              nullptr, stream, prefetch, prefetch_bytes);
 }
 
 extern "C" int mh_layernorm_fwd_fp8(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y,
@@ -478,7 +453,7 @@ extern "C" int mh_layernorm_fwd_fp8(const float* x, int x_L, int x_off, const fl
 
 static int layernorm_fwd_impl(const float* x, int x_L, int x_off, const float* gamma, const float* beta, void* y, int y_L,
                               int y_off, int y_is_f32, float* mean, float* rstd, int B, int n, int dim, float eps, void* y8,
-                              const float* y8_scale, float* y8_amax, void* stream, const void* pf, long pf_bytes) {
+                              const float* y8_scale, float* y8_amax, void* stream) {
     MH_CHECK_ARG(x && gamma && beta && y && mean && rstd, "mh_layernorm_fwd: null pointer");
     MH_CHECK_ARG(dim % 4 == 0 && dim >= 4 && dim <= 2048, "mh_layernorm_fwd: dim %d unsupported", dim);
     MH_CHECK_ARG(B > 0 && n > 0 && x_off + n <= x_L && y_off + n <= y_L, "mh_layernorm_fwd: bad row map");
@@ -488,7 +463,7 @@ static int layernorm_fwd_impl(const float* x, int x_L, int x_off, const float* g
 #define LN_FWD(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, grid, block, 0, s, x, RowMap{x_L, x_off}, gamma, beta, y, \
                                       RowMap{y_L, y_off}, y_is_f32, mean, rstd, B, n, dim, eps, (uint8_t*)y8, y8_scale, y8_amax)
 #define LN_FWD_FAST_(NV, FP8) hipLaunchKernelGGL((ln_fwd_fast_kernel<NV, FP8>), grid, block, 0, s, x, RowMap{x_L, x_off}, gamma, beta, \
-                                                 (bf16_t*)y, RowMap{y_L, y_off}, mean, rstd, B, n, eps, (uint8_t*)y8, y8_scale, y8_amax, pf, pf_bytes)
+                                                 (bf16_t*)y, RowMap{y_L, y_off}, mean, rstd, B, n, eps, (uint8_t*)y8, y8_scale, y8_amax)
 #define LN_FWD_FAST(NV) do { if (y8) LN_FWD_FAST_(NV, true); else LN_FWD_FAST_(NV, false); } while (0)
     const int nvs = ln_nv(dim);
     if (MH_LN_FAST && nvs <= 4 && dim == 256 * nvs && !y_is_f32) {     // the step's own case: straight-line kernel (with or without the e4m3 copy)
@@ -512,7 +487,7 @@ extern "C" long mh_layernorm_bwd_workspace(int rows, int dim) {
 static int layernorm_bwd_impl(const void* dy, int dy_L, int dy_off, int dy_is_f32, const float* x, int x_L, int x_off,
                               const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
                               void* dx_bf16, float* dgamma, float* dbeta, float* dcol, float* workspace, bool partial_only,
-                              int B, int n, int dim, void* stream, const void* pf = nullptr, long pf_bytes = 0) {
+                              int B, int n, int dim, void* stream) {
     const int rows = B * n, nblk = ceil_div(rows, 4 * ROWS_PER_WAVE);
     const size_t lds = (size_t)4 * 3 * dim * sizeof(float);
     dim3 grid(nblk), block(256);
@@ -522,7 +497,7 @@ static int layernorm_bwd_impl(const void* dy, int dy_L, int dy_off, int dy_is_f3
                                       RowMap{x_L, x_off}, gamma, mean, rstd, dres, dx, (bf16_t*)dx_bf16, part, B, n, dim)
 #define LN_BWD_FAST(NV, DEPTH) hipLaunchKernelGGL((ln_bwd_fast_kernel<NV, DEPTH>), grid, block, lds, s, (const bf16_t*)dy, \
                                                   RowMap{dy_L, dy_off}, x, RowMap{x_L, x_off}, gamma, mean, rstd, dres, dx, \
-                                                  (bf16_t*)dx_bf16, part, B, n, pf, pf_bytes)
+                                                  (bf16_t*)dx_bf16, part, B, n)
     const int nvs = ln_nv(dim);
     if (MH_LN_FAST && nvs <= 4 && dim == 256 * nvs && !dy_is_f32 && dres && dx_bf16 && rows % ROWS_PER_WAVE == 0) {
         // the transformer blocks' own case: straight-line kernel, all of a wave's rows in flight (two at dim 1024: registers)
@@ -564,18 +539,6 @@ extern "C" int mh_layernorm_bwd_partial(const void* dy, int dy_L, int dy_off, in
     MH_CHECK_ARG(B > 0 && n > 0 && x_off + n <= x_L && dy_off + n <= dy_L, "mh_layernorm_bwd_partial: bad row map");
     return layernorm_bwd_impl(dy, dy_L, dy_off, dy_is_f32, x, x_L, x_off, gamma, mean, rstd, dres, dx, dx_bf16, nullptr, nullptr,
                               nullptr, workspace, true, B, n, dim, stream);
-}
-
-extern "C" int mh_layernorm_bwd_partial_pf(const void* dy, int dy_L, int dy_off, int dy_is_f32, const float* x, int x_L, int x_off,
-                                           const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
-                                           void* dx_bf16, float* workspace, int B, int n, int dim, const void* prefetch,
-                                           long prefetch_bytes, void* stream) {
-    MH_CHECK_ARG(dy && x && gamma && mean && rstd && dx && workspace, "mh_layernorm_bwd_partial_pf: null pointer");
-    MH_CHECK_ARG(dim % 4 == 0 && dim >= 4 && dim <= 2048, "mh_layernorm_bwd_partial_pf: dim %d unsupported", dim);
-    MH_CHECK_ARG(B > 0 && n > 0 && x_off + n <= x_L && dy_off + n <= dy_L, "mh_layernorm_bwd_partial_pf: bad row map");
-    MH_CHECK_ARG(!prefetch || ((uintptr_t)prefetch % 4 == 0 && prefetch_bytes >= 0), "mh_layernorm_bwd_partial_pf: prefetch range");
-    return layernorm_bwd_impl(dy, dy_L, dy_off, dy_is_f32, x, x_L, x_off, gamma, mean, rstd, dres, dx, dx_bf16, nullptr, nullptr,
-                              nullptr, workspace, true, B, n, dim, stream, prefetch, prefetch_bytes);
 }
 
 extern "C" int mh_colsum_batched(const MhColsumJob* jobs_device, int n_jobs, const uint64_t* blocks_device, int n_blocks,

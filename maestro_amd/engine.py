@@ -207,18 +207,6 @@ class Stack:
         """Gradient slot of the last layer's fc2 bias: it equals colsum(d x_last), produced by the final-LN backward."""
         return self.eng.store.g(self.t.layers[-1][1].net[4].bias) if self.depth else None
 
-    def _weights_of(self, first, last):
-        """The bf16 shadow from parameter ``first`` through parameter ``last`` (neighbours in the flat layout: to_qkv + to_out,
-        net.1 + net.4 of one layer) as ONE read-only range for the LayerNorm launches' weight prefetch; None if they are not."""
-        key = (id(first), id(last))
-        cache = self.__dict__.setdefault("_pf_ranges", {})
-        if key not in cache:
-            ps = self.eng.store
-            a, b = ps.offset.get(id(first)), ps.offset.get(id(last))
-            ok = a is not None and b is not None and 0 <= b - a <= 2 * first.numel() + 4096
-            cache[key] = ps.half[a: b + last.numel()] if ok else None
-        return cache[key]
-
     def forward(self, before_layer=None) -> None:
         """``before_layer(l)``: called ahead of layer l's first launch (the overlapped optimizer's per-layer wait)."""
         eng, ps, M = self.eng, self.eng.store, self.M  # noqa: N806
@@ -231,15 +219,13 @@ class Stack:
                 self._forward_layer_fp8(l, attn, ff, s, x_in, x_mid, x_out)
                 continue
             proj = attn.to_out[0]
-            hip.layernorm_fwd(x_in, M, 0, attn.norm.weight, attn.norm.bias, s["h1"], M, 0, s["mean1"], s["rstd1"], 1, M, dim,
-                              prefetch=self._weights_of(attn.to_qkv.weight, proj.weight))
+            hip.layernorm_fwd(x_in, M, 0, attn.norm.weight, attn.norm.bias, s["h1"], M, 0, s["mean1"], s["rstd1"], 1, M, dim)
             hip.gemm(hip.GEMM_NT, M, 3 * inner, dim, s["h1"], dim, ps.h(attn.to_qkv.weight), dim, s["qkv"], 3 * inner)
             hip.attn_fwd(s["qkv"], s["o"], s["lse"], self.Bn, self.N, self.H, self.Dh, attn.scale)
             hip.gemm(hip.GEMM_NT, M, dim, inner, s["o"], inner, ps.h(proj.weight), inner, x_mid, dim,
                      hip.OUT_F32 | hip.BIAS | hip.RESIDUAL, bias=proj.bias, res=x_in, ldr=dim)
             ln2, fc1, fc2 = ff.net[0], ff.net[1], ff.net[4]
-            hip.layernorm_fwd(x_mid, M, 0, ln2.weight, ln2.bias, s["h2"], M, 0, s["mean2"], s["rstd2"], 1, M, dim,
-                              prefetch=self._weights_of(fc1.weight, fc2.weight))
+            hip.layernorm_fwd(x_mid, M, 0, ln2.weight, ln2.bias, s["h2"], M, 0, s["mean2"], s["rstd2"], 1, M, dim)
             # s["hpre"] receives GELU'(pre-activation): the forward epilogue has the CDF / PDF at hand, the backward multiplies
             hip.gemm(hip.GEMM_NT, M, mlp, dim, s["h2"], dim, ps.h(fc1.weight), dim, s["act"], mlp,
                      hip.BIAS | hip.GELU | hip.AUX_DGELU | eng.aux_flag, bias=fc1.bias, aux_out=s["hpre"], ldaux=mlp)
@@ -356,7 +342,7 @@ class Stack:
                 hip.gemm(hip.GEMM_NN, M, dim, mlp, dh, mlp, ps.h(fc1.weight), dim, self.dh2, dim)
             if defer:   # parameter gradients: partial rows now, one batched reduce per segment (reduce_jobs)
                 hip.layernorm_bwd_partial(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16, s["ws2"],
-                                          1, M, dim, prefetch=self._weights_of(attn.to_qkv.weight, proj.weight))
+                                          1, M, dim)
             else:
                 hip.layernorm_bwd(self.dh2, M, 0, x_mid, M, 0, ln2.weight, s["mean2"], s["rstd2"], cur, mid, mid16,
                                   ps.g(ln2.weight), ps.g(ln2.bias), ps.g(proj.bias), self.ln_ws, 1, M, dim)
@@ -382,10 +368,8 @@ class Stack:
                 hip.gemm(hip.GEMM_NN, M, dim, 3 * inner, dqkv, 3 * inner, ps.h(attn.to_qkv.weight), dim, self.dh2, dim)
             prev_fc2_bias = ps.g(self.t.layers[l - 1][1].net[4].bias) if l > 0 else None  # = colsum(dx_out of layer l-1)
             if defer:
-                below = self.t.layers[l - 1][1] if l > 0 else None      # the MLP weights the layer below is about to read
                 hip.layernorm_bwd_partial(self.dh2, M, 0, x_in, M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid, nxt, nxt16,
-                                          s["ws1"], 1, M, dim,
-                                          prefetch=self._weights_of(below.net[1].weight, below.net[4].weight) if below is not None else None)
+                                          s["ws1"], 1, M, dim)
             else:
                 hip.layernorm_bwd(self.dh2, M, 0, x_in, M, 0, attn.norm.weight, s["mean1"], s["rstd1"], mid, nxt, nxt16,
                                   ps.g(attn.norm.weight), ps.g(attn.norm.bias), prev_fc2_bias, self.ln_ws, 1, M, dim)

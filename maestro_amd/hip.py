@@ -349,15 +349,7 @@ def _esz(t) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ typed wrappers
-PREFETCH = os.environ.get("MAESTRO_PREFETCH", "1") != "0"   # weight prefetch inside the LayerNorm launches (round 6); 0: off (A/B)
-
-
-def layernorm_fwd(x, x_L, x_off, gamma, beta, y, y_L, y_off, mean, rstd, B, n, dim, eps=1e-5, prefetch=None):
-    """``prefetch``: a read-only tensor (the bf16 weights of the GEMMs behind this LayerNorm) to pull into the caches on the way."""
-    if prefetch is not None and PREFETCH:
-        return _hbm_call(f"ln_fwd<{dim}>", float(B) * n * dim * (4 + _esz(y)), "mh_layernorm_fwd_pf", x, _I(x_L), _I(x_off), gamma, beta, y,
-                         _I(y_L), _I(y_off), _I(1 if y.dtype == torch.float32 else 0), mean, rstd, _I(B), _I(n), _I(dim), _F(eps),
-                         prefetch, _L(prefetch.numel() * prefetch.element_size()))
+def layernorm_fwd(x, x_L, x_off, gamma, beta, y, y_L, y_off, mean, rstd, B, n, dim, eps=1e-5):
     _hbm_call(f"ln_fwd<{dim}>", float(B) * n * dim * (4 + _esz(y)), "mh_layernorm_fwd", x, _I(x_L), _I(x_off), gamma, beta, y, _I(y_L),
               _I(y_off), _I(1 if y.dtype == torch.float32 else 0), mean, rstd, _I(B), _I(n), _I(dim), _F(eps))
 
@@ -381,13 +373,8 @@ def layernorm_bwd(dy, dy_L, dy_off, x, x_L, x_off, gamma, mean, rstd, dres, dx, 
               dgamma, dbeta, dcol, workspace, _I(B), _I(n), _I(dim))
 
 
-def layernorm_bwd_partial(dy, dy_L, dy_off, x, x_L, x_off, gamma, mean, rstd, dres, dx, dx_bf16, workspace, B, n, dim, prefetch=None):
+def layernorm_bwd_partial(dy, dy_L, dy_off, x, x_L, x_off, gamma, mean, rstd, dres, dx, dx_bf16, workspace, B, n, dim):
     """LayerNorm backward that leaves (dgamma | dbeta | colsum(dx)) as per-block partial rows in ``workspace`` (see ColsumBatch)."""
-    if prefetch is not None and PREFETCH:
-        return _hbm_call(f"ln_bwd<{dim}>", float(B) * n * dim * (_esz(dy) + 4 + _esz(dres) + 4 + _esz(dx_bf16)),
-                         "mh_layernorm_bwd_partial_pf", dy, _I(dy_L), _I(dy_off), _I(1 if dy.dtype == torch.float32 else 0), x, _I(x_L),
-                         _I(x_off), gamma, mean, rstd, dres, dx, dx_bf16, workspace, _I(B), _I(n), _I(dim), prefetch,
-                         _L(prefetch.numel() * prefetch.element_size()))
     _hbm_call(f"ln_bwd<{dim}>", float(B) * n * dim * (_esz(dy) + 4 + _esz(dres) + 4 + _esz(dx_bf16)), "mh_layernorm_bwd_partial", dy,
               _I(dy_L), _I(dy_off), _I(1 if dy.dtype == torch.float32 else 0), x, _I(x_L), _I(x_off), gamma, mean, rstd, dres, dx,
               dx_bf16, workspace, _I(B), _I(n), _I(dim))

@@ -197,13 +197,19 @@ def _rs_ag_worker(rank, world, port, out, steps):
                 refused = False
             except hip.HipExtensionError:
                 refused = True
-            sd = loop.state_dict()          # the collective form: gathers, then returns the whole Adam state on every rank
+            try:                 # round 6: the loop's state_dict is NOT a collective any more: ungathered, it refuses as well
+                loop.state_dict()
+                refused = False
+            except hip.HipExtensionError:
+                pass
+            loop.gather_state()             # the explicit collective (every rank) ...
+            sd = loop.state_dict()          # ... then the whole Adam state (copies) + the fp32 masters, on whichever rank asks
             m = loop.opt.m.cpu()
             allm = [torch.zeros_like(m) for _ in range(world)]
             dist.all_gather(allm, m)
             res[mode]["moments_same"] = all(torch.equal(allm[0], x) for x in allm) and float(m.abs().sum()) > 0
-            # save -> load into a FRESH loop (same weights) -> both continue: an accumulated step (no hook: the recorded bucket plan
-            # is replayed) and a plain one; parameters must stay equal
+            # save -> load into a FRESH loop (same weights) -> both continue: an accumulated step (no hook: the static bucket cuts
+            # are the same) and a plain one; parameters must stay equal
             ds2, model2 = _build_single_groups()
             loop2 = PretrainLoop(model2, 2, dev, total_steps=50, world_size=world, bucket_mb=1, base_lr=2e-3, exchange_mode=mode)
             loop2.engine.store.flat.copy_(loop.engine.store.flat)
@@ -254,7 +260,7 @@ def test_reduce_scatter_all_gather_plan_equals_the_all_reduce_plan():
         assert r["rs_ag"]["half_ok"] and r["rs_ag"]["moments_same"], rank
         assert r["rs_ag"]["refused"], "FusedAdamW.state_dict() handed out sharded, ungathered moments"
         assert r["rs_ag"]["resumed_rel"] < 1e-6, (rank, r["rs_ag"]["resumed_rel"])     # (atomically accumulated bias gradients: not bit-equal)
-        assert {"exchange_mode", "world", "gathered", "span"} <= set(r["rs_ag"]["state_keys"])
+        assert {"exchange_mode", "world", "span", "t"} <= set(r["rs_ag"]["state_keys"])
         # all of the payload but the short rest of every bucket (< 64 x world elements each) went through the reduce-scatter
         assert r["rs_ag"]["sharded"] > 0 and r["rs_ag"]["whole"] < 128 * r["rs_ag"]["buckets"], (rank, r["rs_ag"])
         assert r["all_reduce"]["sharded"] == 0
