@@ -103,7 +103,8 @@ class InStepTuner:
     its stream; ``finish`` keeps a candidate only where it beats the library's rule (MH_TILE_AUTO) by ``margin`` over all
     launches of that signature, else the rule stays.  Choices land in the process-wide table ``_pick_tile`` consults."""
 
-    CANDIDATES = (TILE_AUTO, TILE_REG_128, TILE_PP_128, TILE_REG_64, TILE_REG_192, TILE_DMA_256)
+    CANDIDATES = (TILE_AUTO, TILE_REG_128, TILE_PP_128, TILE_REG_64, TILE_REG_192, TILE_DMA_256) + (
+        (TILE_SK_DMA_256, TILE_SK_192, TILE_SK_256) if os.environ.get("MAESTRO_INSTEP_SK") == "1" else ())   # round 6: the stream-K tiles
 
     def __init__(self) -> None:
         self.cand, self.ev, self.bad = None, {}, set()
