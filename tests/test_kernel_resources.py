@@ -50,6 +50,22 @@ def test_straight_line_layernorm_kernels_are_in_the_library(kernels):
         assert form in names and names[form]["vgpr_count"] <= 256 and names[form]["private_segment_fixed_size"] == 0, form
 
 
+def test_stream_k_kernels_keep_their_accumulators_in_registers(kernels):
+    """Round 6: the eight-wave stream-K kernel has 256 registers per lane, 128 of them accumulators; written the obvious way
+    (accumulators updated inside one arm of a branch) it spilled 30-250 registers -- some of them the K loop's fragment addresses,
+    reloaded from scratch behind vmcnt(0) in every K step (profiles/r06_experiments.md #3).  All four instantiations must stay
+    spill-free inside two waves per SIMD; the four-wave kernels inside one wave per SIMD."""
+    names = {k["kernel"]: k for k in kernels}
+    for b_kmajor in ("false", "true"):
+        for epi in (0, 1):
+            k = names.get(f"gemm_sk_dma_kernel<{b_kmajor}, {epi}>")
+            assert k is not None, sorted(n for n in names if "gemm_sk" in n)
+            assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0 and k["vgpr_count"] <= 256, k
+            for mt in (6, 8):
+                k4 = names.get(f"gemm_sk_kernel<{b_kmajor}, {mt}, {epi}>")
+                assert k4 is not None and k4["vgpr_spill_count"] == 0 and k4["private_segment_fixed_size"] == 0, (b_kmajor, mt, epi, k4)
+
+
 def _kernel_bodies(asm: str):
     cur, body, out = None, [], {}
     for ln in asm.splitlines():
