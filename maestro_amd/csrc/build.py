@@ -31,6 +31,14 @@ FILE_FLAGS = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectori
               # MFMA, keeps the accumulators' loop phis in VGPRs and shuttles every accumulator through v_accvgpr_write / _read around
               # each MFMA (774 moves in the kernel, 8 per MFMA in the K loop); with it the K loop has none.
               "gemm_sk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# Round 6: no packed fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in the GEMM files.  The f32x4 expressions of the epilogues
+# were selected as packed instructions (4.9 k / 1.5 k / 23.7 k of them in gemm / gemm_pp / gemm_dma); beside MFMAs -- gemm_pp's epilogue runs
+# inside the next tile's main loop, the other kernels' next to the co-resident workgroup's -- a packed instruction costs more issue time
+# than the two scalar ones it replaces (MI355X_MICROARCH.md, constants table).  Same box, four alternating rounds of 30 C3 steps
+# (profiles/r06_experiments.md #13): 17.56 -> 17.34 ms median, bit-identical loss; the flag on the other files changes nothing.
+NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+for _f in ("gemm.hip", "gemm_pp.hip", "gemm_dma.hip"):
+    FILE_FLAGS[_f] = FILE_FLAGS.get(_f, []) + NO_PK_F32
 
 
 def _hipcc() -> str:

@@ -9,6 +9,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 ap = argparse.ArgumentParser()
 ap.add_argument("name"); ap.add_argument("--rev", default=None); ap.add_argument("--flags", default=""); ap.add_argument("--attn-flags", default="")
+ap.add_argument("--only", default="", help="comma-separated source names the extra --flags apply to (default: every file)")
 a = ap.parse_args()
 tmp = Path(tempfile.mkdtemp(prefix=f"variant_{a.name}_"))
 (tmp / "maestro_amd").mkdir(); (tmp / "include").mkdir()
@@ -20,12 +21,17 @@ else:
     shutil.copytree(ROOT / "maestro_amd" / "csrc", tmp / "maestro_amd" / "csrc", ignore=shutil.ignore_patterns("build", "__pycache__"), dirs_exist_ok=True)
     shutil.copytree(ROOT / "include", tmp / "include", dirs_exist_ok=True)
 csrc = tmp / "maestro_amd" / "csrc"
-flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-result"] + a.flags.split()
-attn = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"] + a.attn_flags.split()
+flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-result"]
+only = set(filter(None, a.only.split(",")))
+extra = lambda name: a.flags.split() if not only or name in only else []
+sys.path.insert(0, str(ROOT))
+from maestro_amd.csrc.build import FILE_FLAGS          # the library's own per-file flags (attn.hip, gemm_sk.hip)
+file_flags = {k: list(v) for k, v in FILE_FLAGS.items()}
+file_flags["attn.hip"] = file_flags.get("attn.hip", []) + a.attn_flags.split()
 srcs = sorted(csrc.glob("*.hip"))
 def cc(src):
     obj = src.with_suffix(".o")
-    r = subprocess.run(["hipcc", *flags, *(attn if src.name == "attn.hip" else []), "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
+    r = subprocess.run(["hipcc", *flags, *extra(src.name), *file_flags.get(src.name, []), "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
     if r.returncode: raise RuntimeError(r.stderr)
     return obj
 with ThreadPoolExecutor(4) as ex: objs = list(ex.map(cc, srcs))
