@@ -16,6 +16,19 @@
 // Out-of-range rows / K rows read as zero through the buffer descriptor's extent (no predication anywhere).
 #include "gemm_ring.hpp"
 
+// MH_DMA_PRIO (A/B aid): 0 = raise the priority around every math phase (default); 1 = static priority for the second-dispatched half
+// (waves 4-7), no flips; 2 = no priority at all
+#ifndef MH_DMA_PRIO
+#define MH_DMA_PRIO 0
+#endif
+#if MH_DMA_PRIO == 0
+#define MH_PRIO_UP() __builtin_amdgcn_s_setprio(1)
+#define MH_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
+#else
+#define MH_PRIO_UP() ((void)0)
+#define MH_PRIO_DOWN() ((void)0)
+#endif
+
 namespace {
 
 // (CALLER only makes the instantiations of the two kernels distinct: the host pass of hipcc 7.2 rejects the second request
@@ -108,12 +121,15 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
         // element as the lockstep loop: bit-identical results.
         wait_step(0);
         __builtin_amdgcn_s_barrier();
+#if MH_DMA_PRIO == 1
+        if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
         if (w < 4) {                   // wave-uniform role; both roles execute 2 nk barriers
             for (int t = 0; t < nk; ++t) {
                 load_step(t);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1); math_step(); __builtin_amdgcn_s_setprio(0);
+                MH_PRIO_UP(); math_step(); MH_PRIO_DOWN();
                 if (t + 1 < nk) wait_step(t + 1);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -126,7 +142,7 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, int tile_m, i
                 if (t + 1 < nk) wait_step(t + 1);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1); math_step(); __builtin_amdgcn_s_setprio(0);   // phase 2t+2
+                MH_PRIO_UP(); math_step(); MH_PRIO_DOWN();   // phase 2t+2
                 if (t + 1 < nk) {
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
