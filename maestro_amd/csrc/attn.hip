@@ -27,6 +27,23 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef ATTN_DIAG
 #define ATTN_DIAG 0
 #endif
+// ATTN_LAZY_MAX = 1 (round 6): the forward does NOT follow a running maximum while the scores stay in range.  Every query has a REFERENCE
+// exponent m2 (log2 units, 0 at first); the exp2 argument of a score is s * scale * log2(e) - m2 (one FMA, as before), and as long as every
+// lane's largest argument of the tile lies within ATTN_LAZY_RANGE of it the probabilities are exp2 of that as it stands: no cross-lane
+// maximum, no exp2 for the correction factor, no rescaling of O and of the denominator (fp32 sums and bf16 probabilities keep their
+// RELATIVE precision whatever the common factor 2^-m2 is; the normalisation removes it, lse = (m2 + log2 l) ln 2 carries it).  A tile
+// that leaves the range (wave-uniform branch) moves the reference to its row maximum the classic way -- up at any tile, down only at the
+// first one.  Same box, scripts/bench_attn.py: forward D = 32, N = 1024 155 -> 122 us, N = 400 34.9 -> 31.4; D = 64, N = 256 18.1 -> 16.2.
+// What it costs: the row's largest probability is no longer exactly 1.0 but a bf16-rounded 2^t, so lse / the output carry up to 2^-9
+// relative from it (observed lse 2e-3 -> 3e-3, output 1.9e-2 -> 2.3e-2 on tests/test_kernels_gpu.py's inputs).  Folding scale x log2(e)
+// into Q (bf16) to drop the FMA as well measured no faster and costs 1.5e-2 on lse: not kept.
+// 0 (MH_ATTN_FLAGS="-DATTN_LAZY_MAX=0") keeps the classic online softmax (A/B aid).
+#ifndef ATTN_LAZY_MAX
+#define ATTN_LAZY_MAX 1
+#endif
+#ifndef ATTN_LAZY_RANGE
+#define ATTN_LAZY_RANGE 24.f
+#endif
 // ATTN_SUM_MFMA = 1: the forward's softmax denominators come out of the matrix cores -- one more 16-row block of "V^T" whose row 0 is all
 // ones, so that O^T's extra row 0 is sum_k P^T[k][q] -- instead of one v_add_f32 per score (the kernel is VALU-bound: 5 -> 4 issue slots per
 // score at D = 32; the 4 extra MFMAs per key tile hold the issue port for 32 cycles).  The sum is then over the bf16-rounded probabilities,
@@ -186,7 +203,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        m[qt] = -INFINITY; lsum[qt] = 0.f;
+        m[qt] = ATTN_LAZY_MAX ? 0.f : -INFINITY; lsum[qt] = 0.f;      // lazy: the reference exponent (log2 units), else the raw-score maximum
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[qt][dt] = (f32x4){0, 0, 0, 0};
     }
@@ -213,7 +230,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = (f32x4){0, 0, 0, 0};
+            for (int kt = 0; kt < 4; ++kt) {
+                s[qt][kt] = (f32x4){0, 0, 0, 0};
+            }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -223,6 +242,61 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                 for (int qt = 0; qt < 2; ++qt) s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
             }
         bf16x8 pf[2][2];
+#if ATTN_LAZY_MAX
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            {
+                const f32x4 m4 = {m[qt], m[qt], m[qt], m[qt]};
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) s[qt][kt] = fms4(s[qt][kt], c, m4);     // the exp2 argument relative to the reference
+            }
+            if constexpr (TAIL) {   // keys >= N: probability exp2(-inf) = 0
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kv0 + 16 * kt + 4 * g + r >= N) s[qt][kt][r] = -INFINITY;
+            }
+            float mx = s[qt][0][0];                                  // this lane's largest exp2 argument of the tile
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qt][kt][0]), s[qt][kt][1]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qt][kt][2]), s[qt][kt][3]);
+            }
+            // Wave-uniform: does any lane leave the range?  Upwards at any tile (the reference follows the row maximum, as the classic
+            // form does: alpha <= 1).  Downwards ONLY at the first tile, where the reference is still the arbitrary 0 and nothing has been
+            // accumulated: afterwards it lies within the range of a score that was really there, a tile far below it adds ~0 and is
+            // left alone (moving down with mass accumulated would scale O up by 2^|shift|).  A NaN score compares false and flows
+            // through exp2 into the output, as it does in the reference.
+            const bool first = it == 0;
+            const bool leave = mx > ATTN_LAZY_RANGE || (first && mx < -ATTN_LAZY_RANGE);
+            if (__builtin_amdgcn_ballot_w64(leave) != 0) {
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = first ? fmaxf(mx, -3.0e38f) : fmaxf(mx, 0.f);  // (a first tile has at least one valid key per row: mx is finite)
+                const float alpha = first ? 1.f : exp2_fast(-mx);    // first tile: O and the denominator are still zero
+                m[qt] += mx;
+                const f32x4 mx4 = {mx, mx, mx, mx};
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) s[qt][kt] = fms4(s[qt][kt], 1.f, mx4);
+                if constexpr (SUM_MFMA) ol[qt][0] *= alpha;
+                else lsum[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[qt][dt] = scale4(o[qt][dt], alpha);
+            }
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 t = s[qt][kt];
+                const f32x4 pv = {exp2_fast(t[0]), exp2_fast(t[1]), exp2_fast(t[2]), exp2_fast(t[3])};
+                s[qt][kt] = pv;
+                if constexpr (!SUM_MFMA) { p0 += pv[0]; p1 += pv[1]; p2 += pv[2]; p3 += pv[3]; }
+            }
+            if constexpr (!SUM_MFMA) lsum[qt] += (p0 + p1) + (p2 + p3);
+            pf[qt][0] = pack_acc(s[qt][0], s[qt][1]);
+            pf[qt][1] = pack_acc(s[qt][2], s[qt][3]);
+        }
+#else
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             // running max on the RAW scores (scale > 0 commutes with max); scale and max folded into one FMA per element
@@ -287,6 +361,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             pf[qt][0] = pack_acc(s[qt][0], s[qt][1]);
             pf[qt][1] = pack_acc(s[qt][2], s[qt][3]);
         }
+#endif
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -325,7 +400,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
             u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             *reinterpret_cast<u32x2*>(orow + 16 * dt + 4 * g) = pk;
         }
+#if ATTN_LAZY_MAX
+        if (g == 0) lse[((size_t)b * H + h) * N + q] = m[qt] * 0.6931471805599453f + logf(lt);  // m is the reference exponent, log2 units
+#else
         if (g == 0) lse[((size_t)b * H + h) * N + q] = m[qt] * scale + logf(lt);  // m is a raw-score max
+#endif
     }
 }
 

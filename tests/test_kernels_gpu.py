@@ -126,8 +126,10 @@ def test_attention_fwd_bwd(dev, B, N, H, D):
     hip.attn_fwd(qkv, out, lse, B, N, H, D, scale)
     ref = qkv.float().requires_grad_(True)
     want, want_lse = _attn_ref(ref, scale)
-    assert (out.float() - want).abs().max() < 2e-2, (out.float() - want).abs().max().item()
-    assert (lse - want_lse).abs().max() < 2e-3
+    # (round 6: the forward no longer normalises the probabilities of a tile by its row maximum -- csrc/attn.hip, ATTN_LAZY_MAX -- so a
+    #  row's largest probability is a bf16-rounded 2^t instead of exactly 1.0: observed lse 2.0e-3 -> 3.1e-3, output 1.9e-2 -> 2.3e-2)
+    assert (out.float() - want).abs().max() < 3e-2, (out.float() - want).abs().max().item()
+    assert (lse - want_lse).abs().max() < 5e-3
     dout = _rand(B, N, H * D, seed=7).to(dev).bfloat16()
     delta = torch.zeros(B, H, N, device=dev)
     dqkv = torch.full((B, N, 3, H, D), float("nan"), device=dev, dtype=torch.bfloat16)
@@ -159,6 +161,39 @@ def test_attention_softmax_spike(dev):
     assert torch.isfinite(out.float()).all()
     assert (out.float() - want).abs().max() < 3e-2
     assert ((lse - want_lse).abs() / want_lse.abs().clamp(min=1)).max() < 2e-3
+
+
+@pytest.mark.parametrize("case", ["all_low", "all_high", "rising", "low_then_spike_then_low", "short_low"])
+def test_attention_reference_exponent_moves(dev, case):
+    """The forward keeps a per-query REFERENCE exponent instead of a running maximum and only moves it when a tile's scores leave
+    +-ATTN_LAZY_RANGE around it (csrc/attn.hip): down at the first tile only, up at any tile.  Each case forces one of those moves."""
+    from maestro_amd import hip
+    B, N, H, D = 1, 64 if case == "short_low" else 320, 2, 32
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, N, H, D, generator=g)
+    k = torch.randn(B, N, H, D, generator=g)
+    v = torch.randn(B, N, H, D, generator=g)
+    u = torch.zeros(D); u[0] = 1.0
+    scale = D**-0.5
+    big = 40.0 / scale                        # q.k = +-big^.. : a logit of +-40 (57 in log2 units) from one coordinate
+    if case in ("all_low", "short_low"):      # every logit of every row ~ -40: the first tile moves the reference DOWN
+        q = q * 0.3 + u * big**0.5; k = k * 0.3 - u * big**0.5
+    elif case == "all_high":                  # every logit ~ +40: first tile moves it UP
+        q = q * 0.3 + u * big**0.5; k = k * 0.3 + u * big**0.5
+    elif case == "rising":                    # the row maximum grows by ~30 from tile to tile (64 keys each)
+        q = q * 0.3 + u * big**0.5
+        k = k * 0.3 + u[None, None, None, :] * (big**0.5) * (torch.arange(N) // 64).float()[None, :, None, None] * 0.75
+    else:                                     # ordinary first tile, one dominating key in the third tile, ordinary tiles after it
+        q[0, 7] = q[0, 7] * 0.3 + u * big**0.5
+        k[0, 150] = k[0, 150] * 0.3 + u * big**0.5 * 3.0
+    qkv = torch.stack([q, k, v], dim=2).to(dev).bfloat16()
+    out = torch.zeros(B, N, H * D, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, N, device=dev)
+    hip.attn_fwd(qkv, out, lse, B, N, H, D, scale)
+    want, want_lse = _attn_ref(qkv.float(), scale)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    assert (out.float() - want).abs().max() < 4e-2, (out.float() - want).abs().max().item()
+    assert ((lse - want_lse).abs() / want_lse.abs().clamp(min=1)).max() < 5e-3
 
 
 # ----------------------------------------------------------------------------------------------- patch embed
