@@ -23,7 +23,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 #define ATTN_SCALAR_VALU 1
 #endif
 // ATTN_DIAG (diagnostic builds only, WRONG results; MH_ATTN_FLAGS="-DATTN_DIAG=n"): what is one VALU issue slot per score worth?
-//   bit 0: forward without the row-sum adds;  bit 1: backward without the scale / lse FMA and without the "- delta" add
+//   bit 0: forward without the row-sum adds;  bit 1: backward without the scale / lse FMA and without the "- delta" add;
+//   bit 2: forward (D = 32) without the four denominator MFMAs per tile
 #ifndef ATTN_DIAG
 #define ATTN_DIAG 0
 #endif
@@ -370,12 +371,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][u], o[qt][dt], 0, 0, 0);
             }
+#if !(ATTN_DIAG & 4)       // (bit 2, WRONG results: the forward without the denominator MFMAs -- what are 4 of its 20 MFMAs per tile worth?)
         if constexpr (SUM_MFMA) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) ol[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qt][u], ol[qt], 0, 0, 0);
         }
+#else
+        if constexpr (SUM_MFMA) { ol[0][0] = 1.f; ol[1][0] = 1.f; }
+#endif
     };
     const int nfull = N / 64;
     for (int it = 0; it < nfull; ++it) kv_tile(it, std::false_type{});
