@@ -472,7 +472,9 @@ class EngineBase:
         self._inputs = {}           # per batch key: last device address, or the engine-owned staging copy
         # (round 5: a high-priority main stream -- the first, longest group chain dispatched ahead of the side streams' kernels -- was
         # measured on C3, eager and graph replay, two alternating rounds each: 18.02 / 18.12 against 18.11 / 18.05 ms, i.e. nothing)
-        self.side_streams = [torch.cuda.Stream(device=device) for _ in range(max(0, n_side_streams))]
+        # MAESTRO_SIDE_PRIORITY=-1 (A/B aid): the group streams beside the main one at high priority (default: 0, as the main stream)
+        prio = int(os.environ.get("MAESTRO_SIDE_PRIORITY", "0"))
+        self.side_streams = [torch.cuda.Stream(device=device, priority=prio) for _ in range(max(0, n_side_streams))]
         self._wgrad_stream = torch.cuda.Stream(device=device)   # plan "ovl": deferred weight gradients under the next segment
 
     def _stable_inputs(self, batch: dict) -> dict:
