@@ -26,6 +26,13 @@
 #include "gemm_reg.hpp"
 #include <type_traits>
 
+// MH_PP_PRIO = 1 (round 6): the wave raises its priority over the MFMA body of every K step and drops it before the barrier, as gemm.hip's
+// K loop does: of the two co-resident workgroups the one whose fragments have arrived issues its MFMAs back to back.  Same box, three
+// alternating rounds of 30 C3 steps: 17.24 / 17.12 / 17.15 -> 17.02 / 17.00 / 17.01 ms (profiles/r06_experiments.md #21).  0: A/B aid.
+#ifndef MH_PP_PRIO
+#define MH_PP_PRIO 1
+#endif
+
 namespace {
 
 enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_MULAUX = 2, EPI_F32 = 3 };
@@ -211,6 +218,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR>(tb, wn + 16 * j, 0);
         if constexpr (CHUNK >= 0) epi_loads(chunk_c);
+#if MH_PP_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -257,6 +267,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
             if constexpr (NV > 0) __builtin_amdgcn_sched_group_barrier(0x402, NV, 0);
         }
         ++sidx;
+#if MH_PP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();
         advance();
     };
