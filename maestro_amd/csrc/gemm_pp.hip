@@ -213,13 +213,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
         const unsigned char* ta = smem + cur * TILE_BYTES;
         const unsigned char* tb = smem + (2 + cur) * TILE_BYTES;
         bf16x8 fa[4], fb[4];
+#if MH_PP_PRIO == 2     // (A/B: the window opens before the step's first fragment reads)
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[i] = read_frag<false>(ta, wm + 16 * i, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = read_frag<B_KMAJOR>(tb, wn + 16 * j, 0);
         if constexpr (CHUNK >= 0) epi_loads(chunk_c);
-#if MH_PP_PRIO
-        __builtin_amdgcn_s_setprio(1);
+#if MH_PP_PRIO == 1 || MH_PP_PRIO == 3
+        __builtin_amdgcn_s_setprio(MH_PP_PRIO);      // (3, A/B: the highest level instead of 1)
 #endif
 #pragma unroll
         for (int j = 0; j < 4; ++j)
