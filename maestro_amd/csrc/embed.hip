@@ -237,6 +237,10 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(const float* __restri
 
 // ---- backward pass 1: per image S1 = sum(dz), S2 = sum(dz*z); dgamma/dbeta (atomic). ROWS tokens per wave.
 constexpr int EB_ROWS = 8;
+// NV = ceil(E / 256) four-column chunks per lane (round 6): a lane owns the same columns in every row, so the dgamma / dbeta partial sums
+// of its EB_ROWS rows stay in registers and touch LDS once at the end (they used to be read-modify-written in LDS for every element:
+// two LDS round trips per element in a kernel that streams 8 bytes per element from HBM).  NV = 0: any E (the LDS form).
+template <int NV>
 __global__ __launch_bounds__(256) void embed_bwd_stats_kernel(const float* __restrict__ dxg, const float* __restrict__ y,
                                                               const float* __restrict__ stats, const float* __restrict__ gamma,
                                                               float* __restrict__ sums, float* __restrict__ dgamma,
@@ -247,24 +251,64 @@ __global__ __launch_bounds__(256) void embed_bwd_stats_kernel(const float* __res
     const int bd = blockIdx.y, b = bd / D, d = bd - b * D;
     const float mu = stats[bd * 2], rs = stats[bd * 2 + 1];
     float* rg = red + (size_t)w * 2 * E;
-    for (int c = lane; c < 2 * E; c += 64) rg[c] = 0.f;
     float s1 = 0.f, s2 = 0.f;
     const int l0 = (blockIdx.x * 4 + w) * EB_ROWS;
-    for (int rr = 0; rr < EB_ROWS; ++rr) {
-        const int l = l0 + rr;
-        if (l >= L) break;
-        const float* yr = y + ((size_t)bd * L + l) * E;
-        const float* gr = dxg + ((size_t)b * Lgroup + tok_off + d * L + l) * E;
-        for (int c = lane * 4; c < E; c += 256) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(yr + c);
-            const f32x4 dd = *reinterpret_cast<const f32x4*>(gr + c);
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+    if constexpr (NV > 0) {
+        f32x4 gz[NV], gd[NV], gm[NV];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float z = (v[e] - mu) * rs, dz = dd[e] * gm[e];
-                s1 += dz; s2 += dz * z;
-                rg[c + e] += dd[e] * z;       // lane-private columns: no race inside the wave
-                rg[E + c + e] += dd[e];
+        for (int j = 0; j < NV; ++j) {
+            const int c = lane * 4 + 256 * j;
+            gz[j] = (f32x4){0, 0, 0, 0}; gd[j] = (f32x4){0, 0, 0, 0};
+            gm[j] = c < E ? *reinterpret_cast<const f32x4*>(gamma + c) : (f32x4){0, 0, 0, 0};
+        }
+#pragma unroll 2
+        for (int rr = 0; rr < EB_ROWS; ++rr) {
+            const int l = l0 + rr;
+            if (l >= L) break;
+            const float* yr = y + ((size_t)bd * L + l) * E;
+            const float* gr = dxg + ((size_t)b * Lgroup + tok_off + d * L + l) * E;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int c = lane * 4 + 256 * j;
+                if (c < E) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(yr + c);
+                    const f32x4 dd = *reinterpret_cast<const f32x4*>(gr + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float z = (v[e] - mu) * rs, dz = dd[e] * gm[j][e];
+                        s1 += dz; s2 += dz * z;
+                        gz[j][e] += dd[e] * z;
+                        gd[j][e] += dd[e];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (c < E) {
+                *reinterpret_cast<f32x4*>(rg + c) = gz[j];
+                *reinterpret_cast<f32x4*>(rg + E + c) = gd[j];
+            }
+        }
+    } else {
+        for (int c = lane; c < 2 * E; c += 64) rg[c] = 0.f;
+        for (int rr = 0; rr < EB_ROWS; ++rr) {
+            const int l = l0 + rr;
+            if (l >= L) break;
+            const float* yr = y + ((size_t)bd * L + l) * E;
+            const float* gr = dxg + ((size_t)b * Lgroup + tok_off + d * L + l) * E;
+            for (int c = lane * 4; c < E; c += 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(yr + c);
+                const f32x4 dd = *reinterpret_cast<const f32x4*>(gr + c);
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float z = (v[e] - mu) * rs, dz = dd[e] * gm[e];
+                    s1 += dz; s2 += dz * z;
+                    rg[c + e] += dd[e] * z;       // lane-private columns: no race inside the wave
+                    rg[E + c + e] += dd[e];
+                }
             }
         }
     }
@@ -546,8 +590,19 @@ extern "C" int mh_embed_finish_bwd(const float* dxg, const float* y, const float
     //  [B = 2, D = 1] modality replayed wrongly -- garbage in `sums` from the second replay on, found in round 3 by the order of
     //  the GPU tests; every other node of the graph was fine)
     hipLaunchKernelGGL(zero_f32_kernel, dim3(ceil_div((long)B * D * 2, 256)), dim3(256), 0, s, sums, B * D * 2);
-    hipLaunchKernelGGL(embed_bwd_stats_kernel, dim3(ceil_div(L, 4 * EB_ROWS), B * D), dim3(256), (size_t)8 * E * sizeof(float), s,
-                       dxg, y, stats, gamma, sums, dgamma, dbeta, B, D, L, E, tok_off, Lgroup);
+    {
+        const dim3 grid(ceil_div(L, 4 * EB_ROWS), B * D), block(256);
+        const size_t lds = (size_t)8 * E * sizeof(float);
+#define MH_EB_LAUNCH(NV) hipLaunchKernelGGL(embed_bwd_stats_kernel<NV>, grid, block, lds, s, dxg, y, stats, gamma, sums, dgamma, dbeta, B, D, L, E, tok_off, Lgroup)
+        switch ((E + 255) / 256) {
+            case 1: MH_EB_LAUNCH(1); break;
+            case 2: MH_EB_LAUNCH(2); break;
+            case 3: MH_EB_LAUNCH(3); break;
+            case 4: MH_EB_LAUNCH(4); break;
+            default: MH_EB_LAUNCH(0); break;
+        }
+#undef MH_EB_LAUNCH
+    }
     hipLaunchKernelGGL(embed_bwd_apply_kernel, dim3(ceil_div((long)B * D * L, 4)), dim3(256), 0, s, dxg, y, stats, gamma, sums,
                        (bf16_t*)dyc, B, D, L, E, tok_off, Lgroup);
     MH_LAUNCH_CHECK();

@@ -106,13 +106,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_pp_kernel(GemmParams p) {
     const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, (short)0, p.bias ? p.N * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rcs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.colsum, (short)0, EPI == EPI_MULAUX ? (int)((long)((p.M + 63) / 64) * p.N * 4) : 0, 0x00020000);
-    const int col_nat = wn + 4 * g;                      // natural layout: block X of pair jp at + 32 jp, block Y at + 32 jp + 16
-    const int col_swp = wn + 4 * g + 12 * (g & 1);       // after the 16-lane-row swap: 8 consecutive columns at + 32 jp
+    const int w_s = __builtin_amdgcn_readfirstlane(w);   // the wave's index as a scalar: epi_setup below rebuilds its lane constants
     int e_c = 0, e_aux = 0, e_bias = 0, e_cs = 0;        // per-lane byte offsets of the finished tile (row wm + lm, pair 0, i = 0)
     f32x4 bias_x = {0, 0, 0, 0}, bias_y = {0, 0, 0, 0};  // bias of the current pair's two column blocks
     f32x4 cs_x = {0, 0, 0, 0}, cs_y = {0, 0, 0, 0};      // EPI_MULAUX: column sums over the wave's 64 rows
     u32x4 ld_x = {0, 0, 0, 0}, ld_y = {0, 0, 0, 0};      // residual (f32x4) / aux bytes (first dword) of the chunk in flight
     auto epi_setup = [&](int m0, int n0) {
+        // The lane constants are rebuilt HERE, once per tile, from the lane id (mbcnt) behind an opaque asm: written against the kernel's
+        // `lm` / `g` they stayed live across the whole K loop, and with the priority window (MH_PP_PRIO) the GELU kernel spilled three
+        // of them -- one scratch reload behind a vmcnt(0) at the head of every tile.
+        int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane));
+        const int g = lane >> 4, lm = lane & 15;
+        const int wm = (w_s >> 1) * 64, wn = (w_s & 1) * 64;
+        const int col_nat = wn + 4 * g;                      // natural layout: block X of pair jp at + 32 jp, block Y at + 32 jp + 16
+        const int col_swp = wn + 4 * g + 12 * (g & 1);       // after the 16-lane-row swap: 8 consecutive columns at + 32 jp
         const int row = m0 + wm + lm;
         if constexpr (EPI == EPI_F32) {
             e_c = (row * p.ldc + n0 + col_nat) * 4;
